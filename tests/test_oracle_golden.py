@@ -1,0 +1,97 @@
+"""The CPU oracle against every golden vector generated from the reference itself
+(tests/golden/make_golden.py).  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import case_names, load_case, uniforms, weights_for
+from oracle import ms_hgnn_oracle as O
+
+TOL = 1e-6  # restatement == reference within 1e-6 on all goldens
+
+
+def _close(a, b, tol=TOL):
+    a = a.numpy() if isinstance(a, torch.Tensor) else a
+    err = float(np.max(np.abs(a - b))) if a.size else 0.0
+    assert a.shape == b.shape and err <= tol, (a.shape, b.shape, err)
+
+
+@pytest.mark.parametrize("name", case_names())
+@pytest.mark.parametrize("decomposed", [False, True])
+def test_oracle_matches_reference(name, decomposed):
+    c = load_case(name)
+    sp, sh, nmp = weights_for(name)
+    h, corr = torch.from_numpy(c["h"]), torch.from_numpy(c["corr"])
+    N = h.shape[1]
+    _close(O.affinity(h), c["corr"], 1e-6)
+    if "pair_node_feat" in c:
+        tr = {}
+        nf, fac = O.ms_hgnn_pairwise_forward(sp, h, uniforms(c, "pair"), nmp, decomposed, tr)
+        _close(nf, c["pair_node_feat"])
+        _close(fac, c["pair_factors"])
+        for k in ("xp", "edges", "edge_feat"):
+            _close(tr[k], c[f"pair_{k}"])
+        if nmp == 1:
+            _close(tr["eo"], c["pair_eo"])
+            _close(tr["agg"], c["pair_agg"])
+    for s in c["scales"].tolist():
+        tr = {}
+        nf, fac, H = O.ms_hgnn_hyper_forward(sh, h, corr, s, uniforms(c, f"hyper{s}"), nmp, decomposed, tr)
+        assert np.array_equal(H.numpy(), c[f"hyper{s}_H"]), (name, s)
+        assert np.array_equal(O.topk_incidence_ranked(corr, s).numpy(), c[f"hyper{s}_H"]), (name, s)
+        _close(nf, c[f"hyper{s}_node_feat"])
+        _close(fac, c[f"hyper{s}_factor"])
+        for k in ("xp", "edges", "edge_feat"):
+            _close(tr[k], c[f"hyper{s}_{k}"])
+        if nmp == 1:
+            _close(tr["eo"], c[f"hyper{s}_eo"])
+            _close(tr["agg"], c[f"hyper{s}_agg"])
+        E = 1 if s == N else N
+        assert H.shape == (h.shape[0], E, N) and fac.shape == (h.shape[0], E, 10)
+
+
+def test_uniform_draw_reproduces_reference_stream():
+    """The recorded uniforms are exactly torch.manual_seed(seed); torch.rand(shape) in call order
+    (pairwise first, then each scale) — the RNG contract of SURVEY.md §7."""
+    c = load_case("nba_b10")
+    torch.manual_seed(int(c["seed"]))
+    B, N = c["h"].shape[:2]
+    (shape,) = O.noise_shapes(B, N, None)
+    assert np.array_equal(O.draw_uniform(shape).numpy(), c["pair_U0"])
+    for s in c["scales"].tolist():
+        (shape,) = O.noise_shapes(B, N, s)
+        assert np.array_equal(O.draw_uniform(shape).numpy(), c[f"hyper{s}_U0"])
+
+
+def test_pairwise_incidence_self_loops():
+    H = O.pairwise_incidence(4, 2)
+    assert H.shape == (2, 16, 4)
+    assert H[0, 5, 1] == 2 and H[0, 6].tolist() == [0, 1, 1, 0]
+    assert torch.all(H.sum(-1) == 2)
+
+
+def test_topk_rank_rule_ties_and_nan():
+    corr = torch.tensor([[[1.0, 1.0, 0.5, 1.0], [0.0, float("nan"), 2.0, 2.0],
+                          [3.0, 2.0, 1.0, 0.0], [0.0, 0.0, 0.0, 0.0]]])
+    H = O.topk_incidence_ranked(corr, 2)[0]
+    assert H[0].tolist() == [1, 1, 0, 0]      # lowest index wins ties
+    assert H[1].tolist() == [0, 1, 1, 0]      # NaN ranks first, then the first 2.0
+    assert H[2].tolist() == [1, 1, 0, 0]
+    assert H[3].tolist() == [1, 1, 0, 0]
+    with pytest.raises(RuntimeError):
+        O.topk_incidence_ranked(corr, 5)
+    with pytest.raises(RuntimeError):
+        O.topk_incidence(corr, 5)
+    assert O.topk_incidence_ranked(corr, 0).sum() == 4  # scale < 1 clamps to 1
+    assert O.topk_incidence_ranked(corr, 4).shape == (1, 1, 4)
+
+
+def test_philox_known_answer():
+    """Philox4x32-10 known-answer vectors (Random123 kat_vectors): counter 0 / key 0 and the
+    all-ones case."""
+    import numpy as np
+    # counter (0,0,0,0), key (0,0) -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8
+    u = O.philox_uniform(4, seed=0, offset=0)
+    exp = np.array([0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8], dtype=np.uint64)
+    assert np.array_equal(u, ((exp >> np.uint64(8)).astype(np.float32) * np.float32(2.0 ** -24)))
+    assert u.min() >= 0.0 and u.max() < 1.0
