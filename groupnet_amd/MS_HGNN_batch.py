@@ -1,0 +1,416 @@
+"""Drop-in replacement of the reference's ``model/MS_HGNN_batch.py`` for MI355X.
+
+    from groupnet_amd.MS_HGNN_batch import MS_HGNN_oridinary, MS_HGNN_hyper, MLP
+
+keeps the constructor arguments, ``forward()`` signatures, return tuples and
+``state_dict`` keys of the reference classes (model/MS_HGNN_batch.py:55-198,
+201-229, 270-443), so ``model/GroupNet_nba.py:9,209-248,290-299`` works unchanged
+and ``load_state_dict(strict=True)`` of a reference checkpoint succeeds.  The
+modules are parameter containers plus orchestration: every tensor operation of the
+forward is a hand-written gfx950 kernel of libgroupnet_hip.so (``groupnet_amd.ops``).
+There is no CPU path and no torch-math fallback; CPU tensors raise ``ValueError``.
+
+Differences from the reference that a caller can observe
+  * tensors must be on the GPU (the reference fork only runs on the CPU);
+  * forward-only: outputs carry no autograd graph;
+  * optional ``noise_u=`` lets the caller inject the uniforms of the Gumbel noise.
+    By default they are drawn exactly as the reference does — ``torch.rand`` on the
+    global CPU generator, one ``(B,E,K)`` draw per MLP_dict_softmax call
+    (model/MS_HGNN_batch.py:45,454) — and uploaded; ``set_noise_mode('device', seed)``
+    switches to the on-device Philox stream.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+Tensor = torch.Tensor
+_HDIM_EXTEND = 64      # model/MS_HGNN_batch.py:72,292
+_GUMBEL_TAU = 0.5      # model/MS_HGNN_batch.py:45
+
+
+# ---------------------------------------------------------------------------------------------
+# noise source
+# ---------------------------------------------------------------------------------------------
+class _NoiseState:
+    mode = "host"   # "host": torch.rand on the CPU generator (reference contract); "device": Philox
+    seed = 0
+    offset = 0      # running element offset of the device stream
+
+
+def set_noise_mode(mode: str, seed: Optional[int] = None, offset: int = 0) -> None:
+    """'host' (default, reference-identical stream) or 'device' (Philox4x32-10, no host work)."""
+    if mode not in ("host", "device"):
+        raise ValueError("mode must be 'host' or 'device'")
+    _NoiseState.mode = mode
+    if seed is not None:
+        _NoiseState.seed = int(seed)
+        _NoiseState.offset = int(offset)
+
+
+def _draw_uniform(shape: Tuple[int, int, int], device: torch.device) -> Tensor:
+    if _NoiseState.mode == "host":
+        return torch.rand(shape).float().to(device, non_blocking=True)
+    n = shape[0] * shape[1] * shape[2]
+    u = ops.philox_uniform(shape, _NoiseState.seed, _NoiseState.offset, device)
+    _NoiseState.offset += n
+    return u
+
+
+def _noise_iter(noise_u: Union[None, Tensor, Sequence[Tensor]]) -> Optional[Iterator[Tensor]]:
+    if noise_u is None:
+        return None
+    if isinstance(noise_u, torch.Tensor):
+        return iter([noise_u])
+    return iter(list(noise_u))
+
+
+_warned_grad = False
+
+
+def _check_forward_only(*inputs: Tensor) -> None:
+    global _warned_grad
+    if not torch.is_grad_enabled():
+        return
+    if any(t is not None and t.requires_grad for t in inputs):
+        raise RuntimeError("groupnet_amd MS-HGNN kernels are forward-only: an input requires grad. "
+                           "Call under torch.no_grad() (backward is not built yet).")
+    if not _warned_grad:
+        warnings.warn("groupnet_amd MS-HGNN forward is forward-only; outputs carry no autograd graph.")
+        _warned_grad = True
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers (same names / shapes as the reference so state_dicts interchange)
+# ---------------------------------------------------------------------------------------------
+class MLP(nn.Module):
+    """Stack of nn.Linear with an activation between layers (model/MS_HGNN_batch.py:201-229).
+
+    Inside the MS-HGNN modules an MLP is only a parameter container — the fused HIP chains read
+    its weights.  Called on its own (the reference's L3 model imports it for unrelated heads,
+    model/GroupNet_nba.py:9,31-32) it is ordinary PyTorch layer math on whatever device it is on.
+    """
+
+    def __init__(self, input_dim, output_dim, hidden_size=(1024, 512), activation='relu', discrim=False,
+                 dropout=-1):
+        super().__init__()
+        widths = [input_dim, *hidden_size, output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(widths[:-1], widths[1:]))
+        if activation == 'relu':
+            self.activation = nn.ReLU()
+        elif activation == 'sigmoid':
+            self.activation = nn.Sigmoid()
+        self.sigmoid = nn.Sigmoid() if discrim else None
+        self.dropout = dropout
+
+    def forward(self, x):
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i != last:
+                x = self.activation(x)
+                if self.dropout != -1:
+                    p = min(0.1, self.dropout / 3) if i == 1 else self.dropout
+                    x = nn.functional.dropout(x, p=p, training=True)
+            elif self.sigmoid is not None:
+                x = self.sigmoid(x)
+        return x
+
+
+def _two_layer(mlp: MLP) -> Tuple[nn.Linear, nn.Linear]:
+    if len(mlp.layers) != 2:
+        raise NotImplementedError("the HIP chains are built for MLPs with one hidden layer")
+    return mlp.layers[0], mlp.layers[1]
+
+
+class MLP_dict_softmax(nn.Module):
+    """Edge-type head (model/MS_HGNN_batch.py:31-53): (factor * distribution, distribution)."""
+
+    def __init__(self, input_dim, output_dim, hidden_size=(1024, 512), activation='relu', discrim=False,
+                 dropout=-1, edge_types=5):
+        super().__init__()
+        if input_dim != _HDIM_EXTEND or tuple(hidden_size) != (128,):
+            raise NotImplementedError("HIP edge-MLP chain is specialised to 64 -> 128 -> {64, K, 1}")
+        if not 1 <= edge_types <= 15:
+            raise NotImplementedError("edge_types must be in 1..15")
+        self.bottleneck_dim = edge_types
+        self.MLP_distribution = MLP(input_dim=input_dim, output_dim=edge_types, hidden_size=hidden_size)
+        self.MLP_factor = MLP(input_dim=input_dim, output_dim=1, hidden_size=hidden_size)
+        self.init_MLP = MLP(input_dim=input_dim, output_dim=input_dim, hidden_size=hidden_size)
+        self._pk: Optional[dict] = None
+        self._pk_key = None
+
+    def _packed(self) -> dict:
+        key = _param_key(self.parameters())
+        if self._pk is None or key != self._pk_key:
+            with torch.no_grad():
+                K = self.bottleneck_dim
+                i0, i1 = _two_layer(self.init_MLP)
+                d0, d1 = _two_layer(self.MLP_distribution)
+                f0, f1 = _two_layer(self.MLP_factor)
+                Wd1 = torch.zeros(32, 256, dtype=d1.weight.dtype, device=d1.weight.device)
+                Wd1[:K, :128] = d1.weight
+                Wd1[K, 128:] = f1.weight[0]
+                bd1 = torch.zeros(32, dtype=d1.bias.dtype, device=d1.bias.device)
+                bd1[:K] = d1.bias
+                bd1[K] = f1.bias[0]
+                self._pk = dict(
+                    Wi0p=ops.pack_linear(i0.weight.detach().contiguous()), bi0=i0.bias.detach().clone(),
+                    Wi1p=ops.pack_linear(i1.weight.detach().contiguous()), bi1=i1.bias.detach().clone(),
+                    Wd0p=ops.pack_linear(torch.cat((d0.weight, f0.weight), 0).contiguous()),
+                    bd0=torch.cat((d0.bias, f0.bias), 0).contiguous(),
+                    Wd1p=ops.pack_linear(Wd1), bd1=bd1)
+            self._pk_key = key
+        return self._pk
+
+    def forward(self, x, noise_u: Optional[Tensor] = None):
+        _check_forward_only(x)
+        if x.dim() != 3:
+            raise ValueError("MLP_dict_softmax expects (B, E, 64); the reference's softmax is only "
+                             "well-defined for 3-D input (model/MS_HGNN_batch.py:517-520)")
+        K = self.bottleneck_dim
+        U = noise_u if noise_u is not None else _draw_uniform((x.shape[0], x.shape[1], K), x.device)
+        return ops.edge_mlp_gumbel(x, U, self._packed(), K, _GUMBEL_TAU)
+
+
+class edge_aggregation(nn.Module):
+    """Typed edge -> node aggregation (model/MS_HGNN_batch.py:247-268): cat(H^T feat, ori)."""
+
+    def __init__(self, input_dim, output_dim, hidden_size=(1024, 512), activation='relu', discrim=False,
+                 dropout=-1, edge_types=5):
+        super().__init__()
+        if input_dim != 64:
+            raise NotImplementedError("HIP aggregation kernels are specialised to 64-wide features")
+        self.edge_types = edge_types
+        self.dict_dim = input_dim
+        self.agg_mlp = nn.ModuleList(MLP(input_dim=input_dim, output_dim=input_dim, hidden_size=(128,))
+                                     for _ in range(edge_types))
+        self.mlp = MLP(input_dim=input_dim, output_dim=input_dim, hidden_size=(128,))  # unused, kept for state_dict
+        self._pk: Optional[dict] = None
+        self._pk_key = None
+
+    def _packed(self) -> dict:
+        key = _param_key(self.agg_mlp.parameters())
+        if self._pk is None or key != self._pk_key:
+            with torch.no_grad():
+                l0 = [m.layers[0] for m in self.agg_mlp]
+                l1 = [m.layers[1] for m in self.agg_mlp]
+                self._pk = dict(
+                    W1p=torch.cat([ops.pack_linear(l.weight.detach().contiguous()) for l in l0]),
+                    b1=torch.stack([l.bias.detach() for l in l0]).contiguous(),
+                    W2p=torch.cat([ops.pack_linear(l.weight.detach().contiguous()) for l in l1]),
+                    b2=torch.stack([l.bias.detach() for l in l1]).contiguous())
+            self._pk_key = key
+        return self._pk
+
+    def forward(self, edge_distribution, H, ori):
+        """Returns cat(H^T feat, ori) WITHOUT the division by N (that is edge2node's,
+        model/MS_HGNN_batch.py:120,355).  ``H=None`` selects the implicit pairwise graph."""
+        _check_forward_only(edge_distribution, ori)
+        return self._aggregate(edge_distribution, H, ori, divisor=1.0)
+
+    def _aggregate(self, edge_feat, H, ori, divisor=None):
+        """gather -> typed MLP -> scatter; divisor=None applies the / N of edge2node."""
+        eo = ops.agg_gather(ori, H)
+        feat = ops.agg_mlp(eo, edge_feat, self._packed(), self.edge_types)
+        return ops.agg_scatter(feat, H, ori, divisor)
+
+
+def _param_key(params: Iterable[nn.Parameter]):
+    """Cheap fingerprint of a parameter set: storage address + in-place version counter."""
+    return tuple((p.data_ptr(), p._version) for p in params)
+
+
+class _MessagePassing(nn.Module):
+    """What both reference modules share: one or more node->edge->node rounds
+    (model/MS_HGNN_batch.py:174-195, 425-441)."""
+
+    edge_types: int
+
+    def _build(self, h_dim: int, bottleneck_dim: int, nmp_layers: int) -> None:
+        if h_dim != 64:
+            raise NotImplementedError("the gfx950 kernels are specialised to h_dim == 64 "
+                                      "(every caller in the reference uses 64, model/GroupNet_nba.py:209-248)")
+        if nmp_layers < 1:
+            raise ValueError("nmp_layers must be >= 1")
+        K = self.edge_types
+        self.nmp_mlp_start = MLP_dict_softmax(input_dim=_HDIM_EXTEND, output_dim=h_dim, hidden_size=(128,),
+                                              edge_types=K)
+        rounds = []
+        for _ in range(nmp_layers - 1):
+            rounds.append(MLP(input_dim=h_dim * 2, output_dim=h_dim, hidden_size=(128,)))
+            rounds.append(MLP_dict_softmax(input_dim=_HDIM_EXTEND, output_dim=h_dim, hidden_size=(128,),
+                                           edge_types=K))
+        self.nmp_mlps = nn.ModuleList(rounds)
+        self.nmp_mlp_end = MLP(input_dim=h_dim * 2, output_dim=bottleneck_dim, hidden_size=(128,))
+        self.attention_mlp = nn.ModuleList(MLP(input_dim=_HDIM_EXTEND * 2, output_dim=1, hidden_size=(32,))
+                                           for _ in range(nmp_layers))
+        self.node2edge_start_mlp = nn.ModuleList(MLP(input_dim=h_dim, output_dim=_HDIM_EXTEND, hidden_size=(256,))
+                                                 for _ in range(nmp_layers))
+        self.edge_aggregation_list = nn.ModuleList(
+            edge_aggregation(input_dim=h_dim, output_dim=bottleneck_dim, hidden_size=(128,), edge_types=K)
+            for _ in range(nmp_layers))
+        self._pk_n2e: Dict[int, Tuple[tuple, dict]] = {}
+        self._pk_mlp: Dict[int, Tuple[tuple, dict]] = {}
+
+    # -- packed weights ------------------------------------------------------------------------
+    def _packed_n2e(self, idx: int) -> dict:
+        start, att = self.node2edge_start_mlp[idx], self.attention_mlp[idx]
+        key = _param_key(list(start.parameters()) + list(att.parameters()))
+        hit = self._pk_n2e.get(idx)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                s0, s1 = _two_layer(start)
+                a0, a1 = _two_layer(att)
+                D = _HDIM_EXTEND
+                # attention layer 0 acts on cat(x'_n, e0_e): split it into the node half (with the
+                # bias) and the edge half, which by linearity is applied to x' before the H-pooling
+                Wpq = torch.cat((a0.weight[:, :D], a0.weight[:, D:]), 0).contiguous()
+                bpq = torch.cat((a0.bias, torch.zeros_like(a0.bias)), 0).contiguous()
+                pk = dict(W0p=ops.pack_linear(s0.weight.detach().contiguous()), b0=s0.bias.detach().clone(),
+                          W1p=ops.pack_linear(s1.weight.detach().contiguous()), b1=s1.bias.detach().clone(),
+                          Wpqp=ops.pack_linear(Wpq), bpq=bpq,
+                          w2=a1.weight.detach()[0].contiguous().clone(), b2=float(a1.bias.detach()[0].item()))
+            self._pk_n2e[idx] = (key, pk)
+            hit = self._pk_n2e[idx]
+        return hit[1]
+
+    def _packed_mlp2(self, mlp: MLP) -> dict:
+        key = _param_key(mlp.parameters())
+        hit = self._pk_mlp.get(id(mlp))
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                l0, l1 = _two_layer(mlp)
+                pk = dict(W0p=ops.pack_linear(l0.weight.detach().contiguous()), b0=l0.bias.detach().clone(),
+                          W1p=ops.pack_linear(l1.weight.detach().contiguous()), b1=l1.bias.detach().clone(),
+                          din=l0.in_features, dh=l0.out_features, dout=l1.out_features)
+            self._pk_mlp[id(mlp)] = (key, pk)
+            hit = self._pk_mlp[id(mlp)]
+        return hit[1]
+
+    # -- stages ----------------------------------------------------------------------------------
+    def _node2edge(self, x: Tensor, H: Optional[Tensor], idx: int) -> Tensor:
+        pk = self._packed_n2e(idx)
+        xp, pq = ops.node_mlp(x, pk["W0p"], pk["b0"], pk["W1p"], pk["b1"], pk["Wpqp"], pk["bpq"])
+        return ops.node2edge(xp, pq, H, pk["w2"], pk["b2"])
+
+    def _edge2node(self, edge_feat: Tensor, ori: Tensor, H: Optional[Tensor], idx: int) -> Tensor:
+        return self.edge_aggregation_list[idx]._aggregate(edge_feat, H, ori)
+
+    def _run(self, h: Tensor, H: Optional[Tensor], E: int, noise_u, out: Optional[Tensor] = None
+             ) -> Tuple[Tensor, Tensor]:
+        B = h.shape[0]
+        K = self.edge_types
+        given = _noise_iter(noise_u)
+
+        def next_u() -> Tensor:
+            if given is not None:
+                try:
+                    return next(given)
+                except StopIteration:
+                    raise ValueError(f"noise_u: {self.nmp_layers} uniform tensors of shape ({B},{E},{K}) needed")
+            return _draw_uniform((B, E, K), h.device)
+
+        edge_feat, factors = self.nmp_mlp_start(self._node2edge(h, H, 0), noise_u=next_u())
+        node_feat, idx = h, 0
+        for l, stage in enumerate(self.nmp_mlps):
+            if l % 2 == 0:
+                node_feat = ops.mlp2(self._edge2node(edge_feat, node_feat, H, idx), self._packed_mlp2(stage))
+                idx += 1
+            else:
+                edge_feat, _ = stage(self._node2edge(node_feat, H, idx), noise_u=next_u())
+        node_feat = ops.mlp2(self._edge2node(edge_feat, node_feat, H, idx), self._packed_mlp2(self.nmp_mlp_end),
+                             out=out)
+        return node_feat, factors
+
+
+class MS_HGNN_oridinary(_MessagePassing):
+    """Pairwise (fully connected, self-loops included) message passing — drop-in for the reference
+    class of the same (misspelt) name, model/MS_HGNN_batch.py:55-198.  ``forward(h_states)`` ->
+    ``(node_feat (B,N,bottleneck), factors (B,N*N,6))``.  The N^2 x N incidence the reference
+    rebuilds with numpy on every call (:143-160) is never materialised."""
+
+    def __init__(self, embedding_dim=64, h_dim=64, mlp_dim=1024, bottleneck_dim=1024, activation='relu',
+                 batch_norm=True, dropout=0.0, nmp_layers=4, vis=False):
+        super().__init__()
+        self.mlp_dim = mlp_dim
+        self.h_dim = h_dim
+        self.bottleneck_dim = bottleneck_dim
+        self.embedding_dim = embedding_dim
+        self.nmp_layers = nmp_layers
+        self.batch_norm = batch_norm
+        self.activation = activation
+        self.vis = vis
+        self.hdim_extend = _HDIM_EXTEND
+        self.edge_types = 6   # model/MS_HGNN_batch.py:74
+        self._build(h_dim, bottleneck_dim, nmp_layers)
+
+    # reference-named stage methods (rel_rec / rel_send are accepted and ignored: the graph is implicit)
+    def node2edge(self, x, rel_rec=None, rel_send=None, idx=0):
+        return self._node2edge(x, None, idx)
+
+    def edge2node(self, x, rel_rec, rel_send, ori, idx):
+        return self._edge2node(x, ori, None, idx)
+
+    def forward(self, h_states, noise_u=None, out=None):
+        """``out`` (optional): where node_feat is written, e.g. a column block of the caller's
+        concatenated feature tensor."""
+        _check_forward_only(h_states)
+        ops._req(h_states, "h_states", (None, None, self.h_dim))
+        N = h_states.shape[1]
+        return self._run(h_states, None, N * N, noise_u, out)
+
+
+class MS_HGNN_hyper(_MessagePassing):
+    """Top-k hypergraph message passing at one group size — drop-in for
+    model/MS_HGNN_batch.py:270-443 (listall=False, the only mode the reference runs, :312).
+    ``forward(h_states, corr)`` -> ``(node_feat (B,N,bottleneck), factor (B,E,10), H (B,E,N))``
+    with E = 1 when scale == N, else N."""
+
+    def __init__(self, embedding_dim=64, h_dim=64, mlp_dim=1024, bottleneck_dim=1024, activation='relu',
+                 batch_norm=True, dropout=0.0, nmp_layers=4, scale=2, vis=False, actor_number=11):
+        super().__init__()
+        self.mlp_dim = mlp_dim
+        self.h_dim = h_dim
+        self.bottleneck_dim = bottleneck_dim
+        self.embedding_dim = embedding_dim
+        self.nmp_layers = nmp_layers
+        self.batch_norm = batch_norm
+        self.activation = activation
+        self.scale = scale
+        self.vis = vis
+        # never used by forward, present in reference checkpoints (model/MS_HGNN_batch.py:290-291)
+        self.spatial_embedding = nn.Linear(2, embedding_dim)
+        self.spatial_transform = nn.Linear(h_dim, h_dim)
+        self.hdim_extend = _HDIM_EXTEND
+        self.edge_types = 10  # model/MS_HGNN_batch.py:294
+        self._build(h_dim, bottleneck_dim, nmp_layers)
+        self.listall = False
+
+    def init_adj_attention(self, feat, feat_corr, scale_factor=2):
+        """H (B,E,N) from the affinity matrix (model/MS_HGNN_batch.py:372-388)."""
+        ops._req(feat_corr, "corr", (feat.shape[0], feat.shape[1], feat.shape[1]))
+        return ops.topk_incidence(feat_corr, [int(scale_factor)])[0]
+
+    def node2edge(self, x, H, idx=0):
+        return self._node2edge(x, H, idx)
+
+    def edge2node(self, x, ori, H, idx):
+        return self._edge2node(x, ori, H, idx)
+
+    def forward(self, h_states, corr, noise_u=None, H=None, out=None):
+        """``H`` (optional) lets a caller that already built the incidence for every scale in one
+        fused launch (``ops.affinity_topk``) hand it in; by default it is built here from ``corr``."""
+        _check_forward_only(h_states, corr)
+        ops._req(h_states, "h_states", (None, None, self.h_dim))
+        if H is None:
+            H = self.init_adj_attention(h_states, corr, scale_factor=self.scale)
+        else:
+            ops._req(H, "H", (h_states.shape[0], None, h_states.shape[1]))
+        node_feat, factor = self._run(h_states, H, H.shape[1], noise_u, out)
+        return node_feat, factor, H

@@ -1,0 +1,91 @@
+"""ctypes binding of libgroupnet_hip.so (the C ABI declared in include/groupnet_hip.h).
+
+There is no CPU fallback: if the shared object is missing or a tensor is not on the
+GPU the call raises.  `import torch` must precede loading the library so that it binds
+to the HIP runtime torch has already loaded (same SONAME, libamdhip64.so.7).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch  # noqa: F401  (must be imported before the .so is loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgroupnet_hip.so")
+ABI_VERSION = 1
+
+GN_OK = 0
+GN_ERR_K_RANGE = -3
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_SZ = ctypes.c_size_t
+_U64 = ctypes.c_ulonglong
+
+# name -> (restype, argtypes); mirrors include/groupnet_hip.h one to one
+SIGNATURES = {
+    "gn_abi_version": (_I, []),
+    "gn_strerror": (ctypes.c_char_p, [_I]),
+    "gn_affinity_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "gn_topk_incidence_f32": (_I, [_P, ctypes.POINTER(_P), ctypes.POINTER(_I), _I, _I, _I, _P]),
+    "gn_affinity_topk_f32": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_I), _I, _I, _I, _I, _P]),
+    "gn_packed_elems": (_SZ, [_I, _I]),
+    "gn_pack_linear_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "gn_node_mlp_f32": (_I, [_P] * 9 + [_I, _P]),
+    "gn_node2edge_f32": (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _I, _P]),
+    "gn_edge_mlp_gumbel_f32": (_I, [_P] * 12 + [_I, _I, _F, _P]),
+    "gn_agg_gather_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "gn_agg_mlp_f32": (_I, [_P] * 7 + [_I, _I, _P]),
+    "gn_agg_scatter_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "gn_mlp2_f32": (_I, [_P] * 6 + [_I, _I, _I, _I, _I, _P]),
+    "gn_philox_uniform_f32": (_I, [_P, _SZ, _U64, _U64, _P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class GroupNetHipError(RuntimeError):
+    """A launcher of libgroupnet_hip.so returned a GN_ERR_* code."""
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared object once; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C groupnet_amd/csrc`.  groupnet_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        got = lib.gn_abi_version()
+        if got != ABI_VERSION:
+            raise ImportError(f"libgroupnet_hip.so ABI {got} != expected {ABI_VERSION}; rebuild it")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == GN_OK:
+        return
+    msg = load().gn_strerror(rc).decode()
+    if rc == GN_ERR_K_RANGE:
+        # torch.topk raises RuntimeError("selected index k out of range") — keep the type
+        raise RuntimeError(f"{what}: {msg}")
+    raise GroupNetHipError(f"{what}: {msg} (code {rc})")
+
+
+def stream_handle() -> ctypes.c_void_p:
+    """hipStream_t of torch's current stream (launches join the caller's stream / graph capture)."""
+    return _P(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,623 @@
+// Per-scene graph kernels of the GroupNet MS-HGNN path for gfx950: cosine affinity, top-k
+// hyperedge incidence, attention-weighted node->edge pooling, hyperedge gather / scatter
+// aggregation, and the Philox noise source.  All of them are byte-moving / VALU work bounded
+// by HBM, so the design rules are: coalesced 16-byte global accesses, the
+// scene's N x 64 feature tile and N x N (or E x N) incidence tile staged ONCE through LDS,
+// wavefront-shuffle reductions, and grids of >> 256 workgroups.
+#include "gn_common.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr size_t kLdsBudget = 128 * 1024;  // per workgroup (of the CU's 160 KiB)
+
+// --------------------------------------------------------------------------------------------
+// A0 + A1: affinity and top-k incidence
+// --------------------------------------------------------------------------------------------
+// NaN ranks above every number (torch.topk semantics); ties go to the lower index.
+__device__ __forceinline__ bool beats(float vj, int j, float vc, int c) {
+  const bool nj = vj != vj, nc = vc != vc;
+  if (nj || nc) return (nj && !nc) || (nj && nc && j < c);
+  return vj > vc || (vj == vc && j < c);
+}
+
+struct ScaleList {
+  float* H[GN_MAX_SCALES];
+  int k[GN_MAX_SCALES];  // clamped to >= 1; k == N marks the single all-ones hyperedge
+  int n;
+};
+
+// rank of column c inside `row` (LDS, N entries) and the writes of every scale
+__device__ __forceinline__ void emit_incidence(const float* row, int N, int b, int i, int c, const ScaleList& sl) {
+  const float v = row[c];
+  int rank = 0;
+  for (int j = 0; j < N; ++j) rank += beats(row[j], j, v, c) ? 1 : 0;
+  for (int s = 0; s < sl.n; ++s) {
+    if (sl.k[s] == N) {
+      if (i == 0) sl.H[s][(size_t)b * N + c] = 1.f;
+    } else {
+      sl.H[s][((size_t)b * N + i) * N + c] = rank < sl.k[s] ? 1.f : 0.f;
+    }
+  }
+}
+
+// One workgroup per scene.  f rows are normalised into LDS (stride D+4 floats keeps the
+// 16-byte row reads of different rows on different banks), corr is formed in LDS, optionally
+// written out, and ranked in place.  Needs N*(D+4 + N)*4 bytes of LDS.
+__global__ __launch_bounds__(kBlock) void affinity_topk_kernel(const float* __restrict__ f, float* __restrict__ corr,
+                                                               ScaleList sl, int N, int D) {
+  extern __shared__ __align__(16) float lds[];
+  const int b = blockIdx.x;
+  const int ldq = D + 4;
+  float* q = lds;             // N x ldq
+  float* cr = lds + N * ldq;  // N x N
+  const float* fb = f + (size_t)b * N * D;
+  const int d4 = D >> 2;
+  for (int idx = threadIdx.x; idx < N * d4; idx += kBlock) {
+    const int r = idx / d4, cc = idx - r * d4;
+    *reinterpret_cast<f32x4*>(q + r * ldq + 4 * cc) = *reinterpret_cast<const f32x4*>(fb + (size_t)r * D + 4 * cc);
+  }
+  __syncthreads();
+  // row norms: one wave per row, lanes stride the row
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int r = wave; r < N; r += kBlock / 64) {
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) ss += q[r * ldq + d] * q[r * ldq + d];
+    ss = gn_wave_sum(ss);
+    const float denom = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize eps, GroupNet_nba.py:284
+    for (int d = lane; d < D; d += 64) q[r * ldq + d] = q[r * ldq + d] / denom;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < N * N; idx += kBlock) {
+    const int i = idx / N, j = idx - i * N;
+    const f32x4* a = reinterpret_cast<const f32x4*>(q + i * ldq);
+    const f32x4* c = reinterpret_cast<const f32x4*>(q + j * ldq);
+    float acc = 0.f;
+    for (int d = 0; d < d4; ++d) {
+      const f32x4 x = a[d], y = c[d];
+      acc = fmaf(x[0], y[0], acc);
+      acc = fmaf(x[1], y[1], acc);
+      acc = fmaf(x[2], y[2], acc);
+      acc = fmaf(x[3], y[3], acc);
+    }
+    cr[idx] = acc;
+    if (corr) corr[(size_t)b * N * N + idx] = acc;
+  }
+  if (sl.n == 0) return;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < N * N; idx += kBlock) {
+    const int i = idx / N, c = idx - i * N;
+    emit_incidence(cr + i * N, N, b, i, c, sl);
+  }
+}
+
+// Large-N affinity: one workgroup per (scene, 16-row band); the band and one 64-column
+// panel of q at a time live in LDS.
+__global__ __launch_bounds__(kBlock) void affinity_banded_kernel(const float* __restrict__ f,
+                                                                 float* __restrict__ corr, int N, int D) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int RB = 16, CB = 64;
+  const int b = blockIdx.y, i0 = blockIdx.x * RB;
+  const int ldq = D + 4, d4 = D >> 2;
+  float* qa = lds;             // RB x ldq
+  float* qb = lds + RB * ldq;  // CB x ldq
+  const float* fb = f + (size_t)b * N * D;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto stage = [&](float* dst, int r0, int nr) {
+    for (int idx = threadIdx.x; idx < nr * d4; idx += kBlock) {
+      const int r = idx / d4, cc = idx - r * d4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + r < N) v = *reinterpret_cast<const f32x4*>(fb + (size_t)(r0 + r) * D + 4 * cc);
+      *reinterpret_cast<f32x4*>(dst + r * ldq + 4 * cc) = v;
+    }
+    __syncthreads();
+    for (int r = wave; r < nr; r += kBlock / 64) {
+      float ss = 0.f;
+      for (int d = lane; d < D; d += 64) ss += dst[r * ldq + d] * dst[r * ldq + d];
+      ss = gn_wave_sum(ss);
+      const float denom = fmaxf(sqrtf(ss), 1e-12f);
+      for (int d = lane; d < D; d += 64) dst[r * ldq + d] = dst[r * ldq + d] / denom;
+    }
+    __syncthreads();
+  };
+  stage(qa, i0, RB);
+  for (int j0 = 0; j0 < N; j0 += CB) {
+    stage(qb, j0, CB);
+    for (int idx = threadIdx.x; idx < RB * CB; idx += kBlock) {
+      const int i = idx / CB, j = idx - i * CB;
+      if (i0 + i < N && j0 + j < N) {
+        const f32x4* a = reinterpret_cast<const f32x4*>(qa + i * ldq);
+        const f32x4* c = reinterpret_cast<const f32x4*>(qb + j * ldq);
+        float acc = 0.f;
+        for (int d = 0; d < d4; ++d) {
+          const f32x4 x = a[d], y = c[d];
+          acc = fmaf(x[0], y[0], acc);
+          acc = fmaf(x[1], y[1], acc);
+          acc = fmaf(x[2], y[2], acc);
+          acc = fmaf(x[3], y[3], acc);
+        }
+        corr[((size_t)b * N + i0 + i) * N + j0 + j] = acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Stand-alone top-k incidence: one workgroup per (scene, band of RB rows of corr).
+__global__ __launch_bounds__(kBlock) void topk_incidence_kernel(const float* __restrict__ corr, ScaleList sl, int N,
+                                                                int RB) {
+  extern __shared__ __align__(16) float lds[];  // RB x N
+  const int b = blockIdx.y, i0 = blockIdx.x * RB;
+  const int nr = min(RB, N - i0);
+  const float* src = corr + ((size_t)b * N + i0) * N;
+  for (int idx = threadIdx.x; idx < nr * N; idx += kBlock) lds[idx] = src[idx];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < nr * N; idx += kBlock) {
+    const int i = idx / N, c = idx - i * N;
+    emit_incidence(lds + i * N, N, b, i0 + i, c, sl);
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// A3 second half: attention-weighted node -> edge pooling.  One wave per hyperedge.
+// --------------------------------------------------------------------------------------------
+// Members of the edge (nodes with H != 0) are compacted into LDS; non-members enter the
+// softmax only as exp(0 - max) terms, exactly as softmax(att * H) treats them
+// (MS_HGNN_batch.py:135-137,366-368).
+template <bool PAIRWISE>
+__global__ __launch_bounds__(kBlock) void node2edge_kernel(const float* __restrict__ xp, const float* __restrict__ pq,
+                                                           const float* __restrict__ H, const float* __restrict__ w2,
+                                                           float b2, float* __restrict__ edges, int N, int E,
+                                                           long long total_edges) {
+  extern __shared__ __align__(16) float lds[];
+  const int wave = gn_uniform((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const long long eg_raw = (long long)blockIdx.x * (kBlock / 64) + wave;
+  const bool live = eg_raw < total_edges;  // dead waves redo the last edge and skip the store
+  const long long eg = live ? eg_raw : total_edges - 1;
+  const int b = (int)(eg / E), e = (int)(eg - (long long)b * E);
+  // per-wave LDS: idx[N] (int), hval[N], att[N]
+  float* base = lds + (size_t)wave * 3 * N;
+  int* s_idx = reinterpret_cast<int*>(base);
+  float* s_h = base + N;
+  float* s_att = base + 2 * N;
+
+  int cnt = 0;
+  if (PAIRWISE) {
+    const int i = e / N, j = e - i * N;
+    if (lane == 0) {
+      if (i == j) {
+        s_idx[0] = i;
+        s_h[0] = 2.f;
+      } else {  // ascending node order, as a dense H row would be scanned
+        s_idx[0] = min(i, j);
+        s_h[0] = 1.f;
+        s_idx[1] = max(i, j);
+        s_h[1] = 1.f;
+      }
+    }
+    cnt = (i == j) ? 1 : 2;
+  } else {
+    const float* Hrow = H + ((size_t)b * E + e) * N;
+    for (int n0 = 0; n0 < N; n0 += 64) {
+      const int n = n0 + lane;
+      const float hv = n < N ? Hrow[n] : 0.f;
+      const unsigned long long mask = __ballot(hv != 0.f);
+      if (hv != 0.f) {
+        const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+        s_idx[pos] = n;
+        s_h[pos] = hv;
+      }
+      cnt += __popcll(mask);
+    }
+  }
+  __syncthreads();
+
+  const float* pqb = pq + (size_t)b * N * GN_FEAT;
+  const float* xpb = xp + (size_t)b * N * GN_FEAT;
+  // Q_e = sum_n H[e,n] * Qn_n      (lanes 32..63 hold channel c of Qn)
+  float qe = 0.f;
+  for (int m = 0; m < cnt; ++m) qe = fmaf(s_h[m], pqb[(size_t)s_idx[m] * GN_FEAT + lane], qe);
+  const float qlo = __shfl(qe, 32 + c, GN_WAVE);  // both halves now see Q_e[c]
+  const float w2c = w2[c];
+  // att for two members per step: half h takes member 2*t + h
+  for (int m0 = 0; m0 < cnt; m0 += 2) {
+    const int m = m0 + h;
+    const bool valid = m < cnt;
+    const int n = valid ? s_idx[m] : 0;
+    const float p = pqb[(size_t)n * GN_FEAT + c];
+    float t = valid ? w2c * fmaxf(p + qlo, 0.f) : 0.f;
+    t = gn_half_sum(t);
+    if (valid && c == 0) s_att[m] = t + b2;
+  }
+  __syncthreads();
+  // softmax over all N nodes of v_n = att_n * H[e,n]  (0 for non-members)
+  float mx = cnt < N ? 0.f : -INFINITY;
+  for (int m = lane; m < cnt; m += 64) mx = fmaxf(mx, s_att[m] * s_h[m]);
+  mx = gn_wave_max(mx);
+  float sum = 0.f;
+  for (int m = lane; m < cnt; m += 64) sum += expf(s_att[m] * s_h[m] - mx);
+  sum = gn_wave_sum(sum);
+  sum += (float)(N - cnt) * expf(0.f - mx);
+  // edges[e] = sum_n (softmax_n * H[e,n]) * x'_n ; lane = feature
+  float acc = 0.f;
+  for (int m = 0; m < cnt; ++m) {
+    const float hv = s_h[m];
+    const float wgt = expf(s_att[m] * hv - mx) / sum * hv;
+    acc = fmaf(wgt, xpb[(size_t)s_idx[m] * GN_FEAT + lane], acc);
+  }
+  if (live) edges[(size_t)eg * GN_FEAT + lane] = acc;
+}
+
+// --------------------------------------------------------------------------------------------
+// A5: hyperedge aggregation — gather (eo = H ori) and scatter (out = cat(H^T feat, ori) / N)
+// --------------------------------------------------------------------------------------------
+// A workgroup owns G consecutive scenes x an edge band [e0, e0+TE).  The scenes' ori tiles and
+// the H band are contiguous in HBM, so they stream into LDS as whole 16-byte pieces; each
+// thread then produces float4 outputs that are again contiguous across the workgroup.
+__global__ __launch_bounds__(kBlock) void agg_gather_kernel(const float* __restrict__ ori, const float* __restrict__ H,
+                                                            float* __restrict__ eo, int B, int N, int E, int G,
+                                                            int TE) {
+  extern __shared__ __align__(16) float lds[];
+  const int b0 = blockIdx.x * G, e0 = blockIdx.y * TE;
+  const int g = min(G, B - b0), te = min(TE, E - e0);
+  float* s_ori = lds;                           // g x N x 64
+  float* s_H = lds + (size_t)G * N * GN_FEAT;   // g x te x N
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(ori + (size_t)b0 * N * GN_FEAT);
+    f32x4* dst = reinterpret_cast<f32x4*>(s_ori);
+    for (int idx = threadIdx.x; idx < g * N * (GN_FEAT / 4); idx += kBlock) dst[idx] = src[idx];
+    for (int idx = threadIdx.x; idx < g * te * N; idx += kBlock) {
+      const int s = idx / (te * N), r = idx - s * te * N;
+      s_H[idx] = H[((size_t)(b0 + s) * E + e0) * N + r];
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < g * te * (GN_FEAT / 4); idx += kBlock) {
+    const int d = idx & 15, se = idx >> 4;
+    const int s = se / te, e = se - s * te;
+    const float* hrow = s_H + (size_t)se * N;
+    const f32x4* o4 = reinterpret_cast<const f32x4*>(s_ori + (size_t)s * N * GN_FEAT) + d;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n) {
+      const float hv = hrow[n];
+      const f32x4 v = o4[n * (GN_FEAT / 4)];
+      acc[0] = fmaf(hv, v[0], acc[0]);
+      acc[1] = fmaf(hv, v[1], acc[1]);
+      acc[2] = fmaf(hv, v[2], acc[2]);
+      acc[3] = fmaf(hv, v[3], acc[3]);
+    }
+    reinterpret_cast<f32x4*>(eo + ((size_t)(b0 + s) * E + e0 + e) * GN_FEAT)[d] = acc;
+  }
+}
+
+// Pairwise graph: eo[(i,j)] = ori_i + ori_j (2 ori_i on the diagonal), H never materialised.
+__global__ __launch_bounds__(kBlock) void agg_gather_pairwise_kernel(const float* __restrict__ ori,
+                                                                     float* __restrict__ eo, int N,
+                                                                     long long total4) {
+  const int E = N * N;
+  for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total4;
+       idx += (long long)gridDim.x * kBlock) {
+    const int d = (int)(idx & 15);
+    const long long be = idx >> 4;
+    const int b = (int)(be / E), e = (int)(be - (long long)b * E);
+    const int i = e / N, j = e - i * N;
+    const f32x4* o4 = reinterpret_cast<const f32x4*>(ori + (size_t)b * N * GN_FEAT) + d;
+    const f32x4 a = o4[i * 16], c = o4[j * 16];
+    f32x4 r = {a[0] + c[0], a[1] + c[1], a[2] + c[2], a[3] + c[3]};
+    reinterpret_cast<f32x4*>(eo)[idx] = r;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void agg_scatter_kernel(const float* __restrict__ feat,
+                                                             const float* __restrict__ H,
+                                                             const float* __restrict__ ori, float* __restrict__ out,
+                                                             int B, int N, int E, int G, float fN) {
+  extern __shared__ __align__(16) float lds[];
+  const int b0 = blockIdx.x * G;
+  const int g = min(G, B - b0);
+  float* s_feat = lds;                            // g x E x 64
+  float* s_H = lds + (size_t)G * E * GN_FEAT;     // g x E x N
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(feat + (size_t)b0 * E * GN_FEAT);
+    f32x4* dst = reinterpret_cast<f32x4*>(s_feat);
+    for (int idx = threadIdx.x; idx < g * E * (GN_FEAT / 4); idx += kBlock) dst[idx] = src[idx];
+    const float* hs = H + (size_t)b0 * E * N;
+    for (int idx = threadIdx.x; idx < g * E * N; idx += kBlock) s_H[idx] = hs[idx];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < g * N * 32; idx += kBlock) {
+    const int d = idx & 31, sn = idx >> 5;
+    const int s = sn / N, n = sn - s * N;
+    f32x4 acc;
+    if (d < 16) {
+      acc = {0.f, 0.f, 0.f, 0.f};
+      const float* hcol = s_H + (size_t)s * E * N + n;
+      const f32x4* f4 = reinterpret_cast<const f32x4*>(s_feat + (size_t)s * E * GN_FEAT) + d;
+      for (int e = 0; e < E; ++e) {
+        const float hv = hcol[(size_t)e * N];
+        const f32x4 v = f4[e * 16];
+        acc[0] = fmaf(hv, v[0], acc[0]);
+        acc[1] = fmaf(hv, v[1], acc[1]);
+        acc[2] = fmaf(hv, v[2], acc[2]);
+        acc[3] = fmaf(hv, v[3], acc[3]);
+      }
+    } else {
+      acc = reinterpret_cast<const f32x4*>(ori + ((size_t)(b0 + s) * N + n) * GN_FEAT)[d - 16];
+    }
+    f32x4 r = {acc[0] / fN, acc[1] / fN, acc[2] / fN, acc[3] / fN};
+    reinterpret_cast<f32x4*>(out + ((size_t)(b0 + s) * N + n) * 2 * GN_FEAT)[d] = r;
+  }
+}
+
+// Large-E / pairwise scatter straight from global memory (feat rows are 256-byte lines; every
+// row is read by exactly two nodes in the pairwise case, so the second read is an L2 hit).
+template <bool PAIRWISE>
+__global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const float* __restrict__ feat,
+                                                                    const float* __restrict__ H,
+                                                                    const float* __restrict__ ori,
+                                                                    float* __restrict__ out, int N, int E,
+                                                                    long long total4, float fN) {
+  for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total4;
+       idx += (long long)gridDim.x * kBlock) {
+    const int d = (int)(idx & 31);
+    const long long bn = idx >> 5;
+    const int b = (int)(bn / N), n = (int)(bn - (long long)b * N);
+    f32x4 acc;
+    if (d < 16) {
+      acc = {0.f, 0.f, 0.f, 0.f};
+      const f32x4* f4 = reinterpret_cast<const f32x4*>(feat + (size_t)b * E * GN_FEAT) + d;
+      if (PAIRWISE) {
+        // edges in ascending e: (i,n) for i<n and (n,j) interleave, but fp32 tolerance makes the
+        // order immaterial; (n,n) counts twice (H = 2 on self-loops)
+        for (int j = 0; j < N; ++j) {
+          const f32x4 v = f4[(size_t)(n * N + j) * 16];
+          const f32x4 w = f4[(size_t)(j * N + n) * 16];
+          acc[0] += v[0] + w[0];
+          acc[1] += v[1] + w[1];
+          acc[2] += v[2] + w[2];
+          acc[3] += v[3] + w[3];
+        }
+      } else {
+        const float* hcol = H + (size_t)b * E * N + n;
+        for (int e = 0; e < E; ++e) {
+          const float hv = hcol[(size_t)e * N];
+          if (hv != 0.f) {
+            const f32x4 v = f4[(size_t)e * 16];
+            acc[0] = fmaf(hv, v[0], acc[0]);
+            acc[1] = fmaf(hv, v[1], acc[1]);
+            acc[2] = fmaf(hv, v[2], acc[2]);
+            acc[3] = fmaf(hv, v[3], acc[3]);
+          }
+        }
+      }
+    } else {
+      acc = reinterpret_cast<const f32x4*>(ori + ((size_t)b * N + n) * GN_FEAT)[d - 16];
+    }
+    f32x4 r = {acc[0] / fN, acc[1] / fN, acc[2] / fN, acc[3] / fN};
+    reinterpret_cast<f32x4*>(out)[idx] = r;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// Philox4x32-10 uniforms
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0;
+  c[1] = n1;
+  c[2] = n2;
+  c[3] = n3;
+}
+
+__global__ __launch_bounds__(kBlock) void philox_uniform_kernel(float* __restrict__ U, unsigned long long n,
+                                                                unsigned long long seed, unsigned long long offset,
+                                                                unsigned long long nblk) {
+  const unsigned long long blk0 = offset >> 2;
+  for (unsigned long long t = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; t < nblk;
+       t += (unsigned long long)gridDim.x * kBlock) {
+    const unsigned long long blk = blk0 + t;
+    uint32_t c[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const unsigned long long gidx = blk * 4 + l;
+      if (gidx >= offset && gidx - offset < n) U[gidx - offset] = (float)(c[l] >> 8) * 5.9604644775390625e-08f;
+    }
+  }
+}
+
+int fill_scales(ScaleList& sl, float* const* H_list, const int* k_list, int n_scales, int N) {
+  if (n_scales < 0 || n_scales > GN_MAX_SCALES) return GN_ERR_SHAPE;
+  if (n_scales > 0 && (H_list == nullptr || k_list == nullptr)) return GN_ERR_NULL;
+  sl.n = n_scales;
+  for (int s = 0; s < n_scales; ++s) {
+    if (H_list[s] == nullptr) return GN_ERR_NULL;
+    if (k_list[s] > N) return GN_ERR_K_RANGE;
+    sl.H[s] = H_list[s];
+    sl.k[s] = k_list[s] == N ? N : (k_list[s] < 1 ? 1 : k_list[s]);
+  }
+  return GN_OK;
+}
+
+inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) {
+  long long g = (work_items + per_block - 1) / per_block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int gn_abi_version(void) { return 1; }
+
+extern "C" const char* gn_strerror(int code) {
+  switch (code) {
+    case GN_OK: return "ok";
+    case GN_ERR_NULL: return "null pointer";
+    case GN_ERR_SHAPE: return "unsupported or non-positive size";
+    case GN_ERR_K_RANGE: return "selected index k out of range";
+    case GN_ERR_ALIGN: return "pointer not 16-byte aligned";
+    case GN_ERR_LAUNCH: return "kernel launch failed";
+    case GN_ERR_LDS: return "tile does not fit in LDS";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int gn_affinity_f32(const float* f, float* corr, int B, int N, int D, gn_stream_t stream) {
+  GN_REQUIRE_PTR(f);
+  GN_REQUIRE_PTR(corr);
+  GN_REQUIRE_ALIGNED(f);
+  if (B <= 0 || N <= 0 || D <= 0 || (D & 3) || D > 1024) return GN_ERR_SHAPE;
+  const size_t fused = (size_t)N * (D + 4 + N) * sizeof(float);
+  if (fused <= kLdsBudget) {
+    ScaleList sl;
+    sl.n = 0;
+    gn_allow_big_lds(affinity_topk_kernel);
+    hipLaunchKernelGGL(affinity_topk_kernel, dim3(B), dim3(kBlock), fused, (hipStream_t)stream, f, corr, sl, N, D);
+  } else {
+    const size_t lds = (size_t)(16 + 64) * (D + 4) * sizeof(float);
+    gn_allow_big_lds(affinity_banded_kernel);
+    hipLaunchKernelGGL(affinity_banded_kernel, dim3((N + 15) / 16, B), dim3(kBlock), lds, (hipStream_t)stream, f, corr,
+                       N, D);
+  }
+  return gn_check_launch();
+}
+
+extern "C" int gn_topk_incidence_f32(const float* corr, float* const* H_list, const int* k_list, int n_scales, int B,
+                                     int N, gn_stream_t stream) {
+  GN_REQUIRE_PTR(corr);
+  if (B <= 0 || N <= 0 || n_scales < 1) return GN_ERR_SHAPE;
+  ScaleList sl;
+  const int rc = fill_scales(sl, H_list, k_list, n_scales, N);
+  if (rc != GN_OK) return rc;
+  if ((size_t)N * sizeof(float) > kLdsBudget) return GN_ERR_LDS;
+  int RB = (int)(kLdsBudget / 2 / ((size_t)N * sizeof(float)));
+  RB = RB > N ? N : RB;
+  // enough bands to give the chip >= ~1024 workgroups when B is small
+  while (RB > 8 && (long long)B * ((N + RB - 1) / RB) < 1024) RB = (RB + 1) / 2;
+  gn_allow_big_lds(topk_incidence_kernel);
+  hipLaunchKernelGGL(topk_incidence_kernel, dim3((N + RB - 1) / RB, B), dim3(kBlock), (size_t)RB * N * sizeof(float),
+                     (hipStream_t)stream, corr, sl, N, RB);
+  return gn_check_launch();
+}
+
+extern "C" int gn_affinity_topk_f32(const float* f, float* corr, float* const* H_list, const int* k_list, int n_scales,
+                                    int B, int N, int D, gn_stream_t stream) {
+  GN_REQUIRE_PTR(f);
+  GN_REQUIRE_ALIGNED(f);
+  if (B <= 0 || N <= 0 || D <= 0 || (D & 3) || D > 1024) return GN_ERR_SHAPE;
+  ScaleList sl;
+  const int rc = fill_scales(sl, H_list, k_list, n_scales, N);
+  if (rc != GN_OK) return rc;
+  const size_t fused = (size_t)N * (D + 4 + N) * sizeof(float);
+  if (fused > kLdsBudget) return GN_ERR_LDS;
+  gn_allow_big_lds(affinity_topk_kernel);
+  hipLaunchKernelGGL(affinity_topk_kernel, dim3(B), dim3(kBlock), fused, (hipStream_t)stream, f, corr, sl, N, D);
+  return gn_check_launch();
+}
+
+extern "C" int gn_node2edge_f32(const float* xp, const float* pq, const float* H, const float* w2, float b2,
+                                float* edges, int B, int N, int E, gn_stream_t stream) {
+  GN_REQUIRE_PTR(xp);
+  GN_REQUIRE_PTR(pq);
+  GN_REQUIRE_PTR(w2);
+  GN_REQUIRE_PTR(edges);
+  if (B <= 0 || N <= 0 || E <= 0) return GN_ERR_SHAPE;
+  if (H == nullptr && (long long)E != (long long)N * N) return GN_ERR_SHAPE;
+  const size_t lds = (size_t)(kBlock / 64) * 3 * N * sizeof(float);
+  if (lds > kLdsBudget) return GN_ERR_LDS;
+  const long long total = (long long)B * E;
+  const long long grid = (total + 3) / 4;
+  if (grid > 0x7fffffffLL) return GN_ERR_SHAPE;
+  gn_allow_big_lds(node2edge_kernel<false>);
+  gn_allow_big_lds(node2edge_kernel<true>);
+  if (H)
+    hipLaunchKernelGGL((node2edge_kernel<false>), dim3((unsigned)grid), dim3(kBlock), lds, (hipStream_t)stream, xp, pq,
+                       H, w2, b2, edges, N, E, total);
+  else
+    hipLaunchKernelGGL((node2edge_kernel<true>), dim3((unsigned)grid), dim3(kBlock), lds, (hipStream_t)stream, xp, pq,
+                       H, w2, b2, edges, N, E, total);
+  return gn_check_launch();
+}
+
+extern "C" int gn_agg_gather_f32(const float* ori, const float* H, float* eo, int B, int N, int E,
+                                 gn_stream_t stream) {
+  GN_REQUIRE_PTR(ori);
+  GN_REQUIRE_PTR(eo);
+  GN_REQUIRE_ALIGNED(ori);
+  GN_REQUIRE_ALIGNED(eo);
+  if (B <= 0 || N <= 0 || E <= 0) return GN_ERR_SHAPE;
+  if (H == nullptr) {
+    if ((long long)E != (long long)N * N) return GN_ERR_SHAPE;
+    const long long total4 = (long long)B * E * 16;
+    hipLaunchKernelGGL(agg_gather_pairwise_kernel, dim3(capped_grid(total4, kBlock * 4)), dim3(kBlock), 0,
+                       (hipStream_t)stream, ori, eo, N, total4);
+    return gn_check_launch();
+  }
+  const size_t ori_b = (size_t)N * GN_FEAT * sizeof(float);
+  if (ori_b + (size_t)N * sizeof(float) > kLdsBudget) return GN_ERR_LDS;
+  int G = 1, TE = E;
+  const size_t per_scene = ori_b + (size_t)E * N * sizeof(float);
+  if (per_scene <= kLdsBudget) {
+    // several scenes per workgroup while the tile stays <= 24 KiB and the grid stays >= 1024
+    while (G < 16 && (size_t)(2 * G) * per_scene <= 24 * 1024 && (B + 2 * G - 1) / (2 * G) >= 1024) G *= 2;
+  } else {
+    TE = (int)((kLdsBudget - ori_b) / ((size_t)N * sizeof(float)));
+    if (TE < 1) return GN_ERR_LDS;
+  }
+  const size_t lds = (size_t)G * ori_b + (size_t)G * TE * N * sizeof(float);
+  gn_allow_big_lds(agg_gather_kernel);
+  hipLaunchKernelGGL(agg_gather_kernel, dim3((B + G - 1) / G, (E + TE - 1) / TE), dim3(kBlock), lds,
+                     (hipStream_t)stream, ori, H, eo, B, N, E, G, TE);
+  return gn_check_launch();
+}
+
+extern "C" int gn_agg_scatter_f32(const float* feat, const float* H, const float* ori, float* out, int B, int N, int E,
+                                  float divisor, gn_stream_t stream) {
+  GN_REQUIRE_PTR(feat);
+  GN_REQUIRE_PTR(ori);
+  GN_REQUIRE_PTR(out);
+  GN_REQUIRE_ALIGNED(feat);
+  GN_REQUIRE_ALIGNED(ori);
+  GN_REQUIRE_ALIGNED(out);
+  if (B <= 0 || N <= 0 || E <= 0 || !(divisor != 0.f)) return GN_ERR_SHAPE;
+  const long long total4 = (long long)B * N * 32;
+  if (H == nullptr) {
+    if ((long long)E != (long long)N * N) return GN_ERR_SHAPE;
+    hipLaunchKernelGGL((agg_scatter_direct_kernel<true>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, feat, H, ori, out, N, E, total4, divisor);
+    return gn_check_launch();
+  }
+  const size_t per_scene = (size_t)E * (GN_FEAT + N) * sizeof(float);
+  if (per_scene > kLdsBudget / 2) {
+    hipLaunchKernelGGL((agg_scatter_direct_kernel<false>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, feat, H, ori, out, N, E, total4, divisor);
+    return gn_check_launch();
+  }
+  int G = 1;
+  while (G < 16 && (size_t)(2 * G) * per_scene <= 24 * 1024 && (B + 2 * G - 1) / (2 * G) >= 1024) G *= 2;
+  gn_allow_big_lds(agg_scatter_kernel);
+  hipLaunchKernelGGL(agg_scatter_kernel, dim3((B + G - 1) / G), dim3(kBlock), (size_t)G * per_scene,
+                     (hipStream_t)stream, feat, H, ori, out, B, N, E, G, divisor);
+  return gn_check_launch();
+}
+
+extern "C" int gn_philox_uniform_f32(float* U, size_t n, unsigned long long seed, unsigned long long offset,
+                                     gn_stream_t stream) {
+  GN_REQUIRE_PTR(U);
+  if (n == 0) return GN_ERR_SHAPE;
+  const unsigned long long nblk = ((offset + n + 3) >> 2) - (offset >> 2);
+  hipLaunchKernelGGL(philox_uniform_kernel, dim3(capped_grid((long long)nblk, kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, U, (unsigned long long)n, seed, offset, nblk);
+  return gn_check_launch();
+}

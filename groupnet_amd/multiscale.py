@@ -1,0 +1,102 @@
+"""The multiscale block around the path: what ``PastEncoder.forward`` does between computing the
+agent embedding and concatenating the per-scale features (model/GroupNet_nba.py:284-311).
+
+    corr  = normalize(f) normalize(f)^T                         :284-286
+    inter = MS_HGNN_oridinary(f)                                :290
+    hyper_s, H_s = MS_HGNN_hyper_s(f, corr)  for each scale     :293-299
+    final = cat(f, inter, hyper_1, ...)                         :301-309
+    new_H = cat(H_1, H_2, ...) on dim 1                         :296,299
+
+MI355X-first choices: affinity and the incidence of EVERY scale come from one fused launch
+(corr never makes a second trip through HBM); the 1+S modules are independent given (f, corr, H_s),
+so they are issued on separate HIP streams and overlap on the 256 CUs (the hyper modules have only
+B*N edge rows each and would leave most of the chip idle if serialised behind one another).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .MS_HGNN_batch import MS_HGNN_hyper, MS_HGNN_oridinary, _NoiseState, _check_forward_only
+
+Tensor = torch.Tensor
+
+
+class MultiScaleHGNN(nn.Module):
+    """One pairwise module + one hyper module per scale on the same (f, corr).
+
+    ``forward(f)`` -> ``(final_feature (B, N, 64*(2+S)), new_H (B, sum_s E_s, N))``.
+    Unlike ``PastEncoder`` (three scales at most, model/GroupNet_nba.py:218-248) any number of
+    scales up to 8 is accepted (BASELINE configs 4 and 5 use four).
+    """
+
+    def __init__(self, hyper_scales: Sequence[int] = (2, 5, 11), h_dim: int = 64, nmp_layers: int = 1,
+                 concurrent: bool = True):
+        super().__init__()
+        if not 0 <= len(hyper_scales) <= 8:
+            raise ValueError("0..8 scales")
+        self.hyper_scales = [int(s) for s in hyper_scales]
+        self.h_dim = h_dim
+        # same constructor arguments as PastEncoder.__init__ (model/GroupNet_nba.py:209-248)
+        self.interaction = MS_HGNN_oridinary(embedding_dim=16, h_dim=h_dim, mlp_dim=64, bottleneck_dim=h_dim,
+                                             batch_norm=0, nmp_layers=nmp_layers)
+        self.interaction_hyper = nn.ModuleList(
+            MS_HGNN_hyper(embedding_dim=h_dim, h_dim=h_dim, mlp_dim=64, bottleneck_dim=h_dim, batch_norm=0,
+                          nmp_layers=nmp_layers, scale=s) for s in self.hyper_scales)
+        self.concurrent = concurrent
+        self._streams: List[torch.cuda.Stream] = []
+
+    @property
+    def out_features(self) -> int:
+        return self.h_dim * (2 + len(self.hyper_scales))
+
+    def noise_shapes(self, B: int, N: int) -> List[Tuple[int, int, int]]:
+        """(B,E,K) of the uniforms each module draws per message-passing round, pairwise first."""
+        out = [(B, N * N, self.interaction.edge_types)]
+        for s in self.hyper_scales:
+            out.append((B, 1 if s == N else N, 10))
+        return out
+
+    def _side_streams(self, n: int, device) -> List[torch.cuda.Stream]:
+        if len(self._streams) < n or (self._streams and self._streams[0].device != device):
+            self._streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return self._streams[:n]
+
+    def forward(self, f: Tensor, noise_u: Optional[Sequence] = None) -> Tuple[Tensor, Optional[Tensor]]:
+        """``noise_u``: optional list with one entry per module (pairwise first), each a tensor or a
+        list of ``nmp_layers`` tensors; default draws as the modules do (reference order)."""
+        _check_forward_only(f)
+        ops._req(f, "f", (None, None, self.h_dim))
+        B, N, D = f.shape
+        S = len(self.hyper_scales)
+        nmp = self.interaction.nmp_layers
+        if noise_u is None:
+            # reference order: every draw of the pairwise module first, then scale by scale
+            from .MS_HGNN_batch import _draw_uniform
+            noise_u = [[_draw_uniform(shp, f.device) for _ in range(nmp)] for shp in self.noise_shapes(B, N)]
+        elif len(noise_u) != 1 + S:
+            raise ValueError(f"noise_u: need {1 + S} entries (pairwise + one per scale)")
+        corr, Hs = (ops.affinity_topk(f, self.hyper_scales) if S else (None, []))
+        final = torch.empty((B, N, self.out_features), dtype=f.dtype, device=f.device)
+        final[..., :D].copy_(f)
+        cols = [final[..., D * (1 + i):D * (2 + i)] for i in range(1 + S)]   # written in place by the last MLP
+        main = torch.cuda.current_stream(f.device)
+        if self.concurrent and S > 0:
+            side = self._side_streams(S, f.device)
+            for st in side:
+                st.wait_stream(main)
+            for i, (mod, H, st) in enumerate(zip(self.interaction_hyper, Hs, side)):
+                with torch.cuda.stream(st):
+                    mod(f, corr, noise_u=noise_u[1 + i], H=H, out=cols[1 + i])
+            self.interaction(f, noise_u=noise_u[0], out=cols[0])
+            for st in side:
+                main.wait_stream(st)
+        else:
+            self.interaction(f, noise_u=noise_u[0], out=cols[0])
+            for i, (mod, H) in enumerate(zip(self.interaction_hyper, Hs)):
+                mod(f, corr, noise_u=noise_u[1 + i], H=H, out=cols[1 + i])
+        new_H = torch.cat(Hs, dim=1) if S else None
+        return final, new_H

@@ -1,0 +1,248 @@
+"""Python faces of the HIP kernels: argument checking, output allocation, launch.
+
+One function per C-ABI entry point of include/groupnet_hip.h.  Tensors must be fp32,
+contiguous and on a HIP device; anything else raises ValueError (the reference would
+instead crash on device tensors, SURVEY.md §8b "Errors").  Nothing here touches the
+CPU oracle or falls back to torch math.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import _P, check, load, stream_handle
+
+Tensor = torch.Tensor
+FEAT = 64
+
+
+def _req(t: Tensor, name: str, shape: Optional[Sequence[Optional[int]]] = None) -> Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: must live on the GPU (got device {t.device}); groupnet_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name}: must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if shape is not None:
+        if t.dim() != len(shape) or any(s is not None and int(d) != int(s) for d, s in zip(t.shape, shape)):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def _same_device(*ts: Tensor) -> None:
+    dev = ts[0].device
+    for t in ts[1:]:
+        if t is not None and t.device != dev:
+            raise ValueError(f"tensors on different devices: {dev} vs {t.device}")
+
+
+def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
+    return _P(0 if t is None else t.data_ptr())
+
+
+# ---- A0 / A1 -----------------------------------------------------------------------------------
+def affinity(f: Tensor) -> Tensor:
+    """corr = normalize(f) @ normalize(f)^T   (model/GroupNet_nba.py:284-286)."""
+    _req(f, "f", (None, None, None))
+    B, N, D = f.shape
+    corr = torch.empty((B, N, N), dtype=f.dtype, device=f.device)
+    with torch.cuda.device(f.device):
+        check(load().gn_affinity_f32(_ptr(f), _ptr(corr), B, N, D, stream_handle()), "gn_affinity_f32")
+    return corr
+
+
+def _alloc_incidence(B: int, N: int, scales: Sequence[int], like: Tensor) -> List[Tensor]:
+    out = []
+    for s in scales:
+        s = int(s)
+        if s > N:
+            raise RuntimeError("selected index k out of range")  # what torch.topk raises (MS_HGNN_batch.py:382)
+        E = 1 if s == N else N
+        out.append(torch.empty((B, E, N), dtype=like.dtype, device=like.device))
+    return out
+
+
+def _scale_args(Hs: List[Tensor], scales: Sequence[int]):
+    n = len(Hs)
+    Hl = (_P * n)(*[h.data_ptr() for h in Hs])
+    kl = (ctypes.c_int * n)(*[int(s) for s in scales])
+    return Hl, kl, n
+
+
+def topk_incidence(corr: Tensor, scales: Sequence[int]) -> List[Tensor]:
+    """H per scale from corr (MS_HGNN_hyper.init_adj_attention, model/MS_HGNN_batch.py:372-388)."""
+    _req(corr, "corr", (None, None, None))
+    B, N, N2 = corr.shape
+    if N != N2:
+        raise ValueError(f"corr: expected (B,N,N), got {tuple(corr.shape)}")
+    if not 1 <= len(scales) <= 8:
+        raise ValueError("between 1 and 8 scales per call")
+    Hs = _alloc_incidence(B, N, scales, corr)
+    Hl, kl, n = _scale_args(Hs, scales)
+    with torch.cuda.device(corr.device):
+        check(load().gn_topk_incidence_f32(_ptr(corr), Hl, kl, n, B, N, stream_handle()), "gn_topk_incidence_f32")
+    return Hs
+
+
+def affinity_topk(f: Tensor, scales: Sequence[int], want_corr: bool = True) -> Tuple[Optional[Tensor], List[Tensor]]:
+    """Fused A0+A1: f -> (corr, [H_s]) in one launch."""
+    _req(f, "f", (None, None, None))
+    B, N, D = f.shape
+    corr = torch.empty((B, N, N), dtype=f.dtype, device=f.device) if want_corr else None
+    Hs = _alloc_incidence(B, N, scales, f)
+    Hl, kl, n = _scale_args(Hs, scales)
+    with torch.cuda.device(f.device):
+        check(load().gn_affinity_topk_f32(_ptr(f), _ptr(corr), Hl, kl, n, B, N, D, stream_handle()),
+              "gn_affinity_topk_f32")
+    return corr, Hs
+
+
+# ---- weight packing ------------------------------------------------------------------------------
+def pack_linear(W: Tensor, col_offset: int = 0, in_features: Optional[int] = None) -> Tensor:
+    """Packed image of an nn.Linear weight (out x in), or of the column block
+    [col_offset, col_offset + in_features) of it."""
+    _req(W, "W", (None, None))
+    out_f, ld = W.shape
+    in_f = ld - col_offset if in_features is None else in_features
+    lib = load()
+    Wp = torch.empty(lib.gn_packed_elems(out_f, in_f), dtype=W.dtype, device=W.device)
+    with torch.cuda.device(W.device):
+        check(lib.gn_pack_linear_f32(_ptr(W), _ptr(Wp), out_f, in_f, ld, col_offset, stream_handle()),
+              "gn_pack_linear_f32")
+    return Wp
+
+
+# ---- A3 ------------------------------------------------------------------------------------------
+def node_mlp(x: Tensor, W0p, b0, W1p, b1, Wpqp, bpq) -> Tuple[Tensor, Tensor]:
+    _req(x, "x", (None, None, FEAT))
+    rows = x.shape[0] * x.shape[1]
+    xp = torch.empty_like(x)
+    pq = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(load().gn_node_mlp_f32(_ptr(x), _ptr(W0p), _ptr(b0), _ptr(W1p), _ptr(b1), _ptr(Wpqp), _ptr(bpq),
+                                     _ptr(xp), _ptr(pq), rows, stream_handle()), "gn_node_mlp_f32")
+    return xp, pq
+
+
+def node2edge(xp: Tensor, pq: Tensor, H: Optional[Tensor], w2: Tensor, b2: float) -> Tensor:
+    """edges (B,E,64).  H=None selects the implicit pairwise graph (E = N*N)."""
+    _req(xp, "xp", (None, None, FEAT))
+    _req(pq, "pq", tuple(xp.shape))
+    B, N, _ = xp.shape
+    if H is None:
+        E = N * N
+    else:
+        _req(H, "H", (B, None, N))
+        E = H.shape[1]
+    _req(w2, "w2", (32,))
+    _same_device(xp, pq, H, w2)
+    edges = torch.empty((B, E, FEAT), dtype=xp.dtype, device=xp.device)
+    with torch.cuda.device(xp.device):
+        check(load().gn_node2edge_f32(_ptr(xp), _ptr(pq), _ptr(H), _ptr(w2), float(b2), _ptr(edges), B, N, E,
+                                      stream_handle()), "gn_node2edge_f32")
+    return edges
+
+
+# ---- A4 ------------------------------------------------------------------------------------------
+def edge_mlp_gumbel(edges: Tensor, U: Tensor, pk: dict, K: int, tau: float = 0.5) -> Tuple[Tensor, Tensor]:
+    _req(edges, "edges", (None, None, FEAT))
+    B, E, _ = edges.shape
+    _req(U, "noise_u", (B, E, K))
+    _same_device(edges, U)
+    edge_feat = torch.empty((B, E, K), dtype=edges.dtype, device=edges.device)
+    dist = torch.empty_like(edge_feat)
+    with torch.cuda.device(edges.device):
+        check(load().gn_edge_mlp_gumbel_f32(_ptr(edges), _ptr(U), _ptr(pk["Wi0p"]), _ptr(pk["bi0"]), _ptr(pk["Wi1p"]),
+                                            _ptr(pk["bi1"]), _ptr(pk["Wd0p"]), _ptr(pk["bd0"]), _ptr(pk["Wd1p"]),
+                                            _ptr(pk["bd1"]), _ptr(edge_feat), _ptr(dist), B * E, K, float(tau),
+                                            stream_handle()), "gn_edge_mlp_gumbel_f32")
+    return edge_feat, dist
+
+
+# ---- A5 ------------------------------------------------------------------------------------------
+def agg_gather(ori: Tensor, H: Optional[Tensor]) -> Tensor:
+    _req(ori, "ori", (None, None, FEAT))
+    B, N, _ = ori.shape
+    if H is None:
+        E = N * N
+    else:
+        _req(H, "H", (B, None, N))
+        E = H.shape[1]
+        _same_device(ori, H)
+    eo = torch.empty((B, E, FEAT), dtype=ori.dtype, device=ori.device)
+    with torch.cuda.device(ori.device):
+        check(load().gn_agg_gather_f32(_ptr(ori), _ptr(H), _ptr(eo), B, N, E, stream_handle()), "gn_agg_gather_f32")
+    return eo
+
+
+def agg_mlp(eo: Tensor, edge_feat: Tensor, pk: dict, K: int) -> Tensor:
+    _req(eo, "eo", (None, None, FEAT))
+    B, E, _ = eo.shape
+    _req(edge_feat, "edge_feat", (B, E, K))
+    _same_device(eo, edge_feat)
+    feat = torch.empty_like(eo)
+    with torch.cuda.device(eo.device):
+        check(load().gn_agg_mlp_f32(_ptr(eo), _ptr(edge_feat), _ptr(pk["W1p"]), _ptr(pk["b1"]), _ptr(pk["W2p"]),
+                                    _ptr(pk["b2"]), _ptr(feat), B * E, K, stream_handle()), "gn_agg_mlp_f32")
+    return feat
+
+
+def agg_scatter(feat: Tensor, H: Optional[Tensor], ori: Tensor, divisor: Optional[float] = None) -> Tensor:
+    """cat(H^T feat, ori) / divisor; divisor defaults to N (edge2node, model/MS_HGNN_batch.py:120,355)."""
+    _req(ori, "ori", (None, None, FEAT))
+    B, N, _ = ori.shape
+    if H is None:
+        E = N * N
+    else:
+        _req(H, "H", (B, None, N))
+        E = H.shape[1]
+    _req(feat, "feat", (B, E, FEAT))
+    _same_device(feat, ori, H)
+    out = torch.empty((B, N, 2 * FEAT), dtype=ori.dtype, device=ori.device)
+    with torch.cuda.device(ori.device):
+        check(load().gn_agg_scatter_f32(_ptr(feat), _ptr(H), _ptr(ori), _ptr(out), B, N, E,
+                                        float(N if divisor is None else divisor), stream_handle()), "gn_agg_scatter_f32")
+    return out
+
+
+# ---- A6 ------------------------------------------------------------------------------------------
+def mlp2(x: Tensor, pk: dict, out: Optional[Tensor] = None) -> Tensor:
+    """y = W1 relu(W0 x + b0) + b1 over the last dim of x.  ``out`` may be a last-dim slice of a
+    contiguous tensor (row stride > dout): the kernel writes the column block in place."""
+    din, dh, dout = pk["din"], pk["dh"], pk["dout"]
+    _req(x, "x")
+    if x.shape[-1] != din:
+        raise ValueError(f"x: last dim {x.shape[-1]} != {din}")
+    rows = x.numel() // din
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (dout,), dtype=x.dtype, device=x.device)
+        ldy = dout
+    else:
+        if not (out.is_cuda and out.dtype == torch.float32 and out.device == x.device):
+            raise ValueError("out: must be a float32 tensor on x's device")
+        if tuple(out.shape) != tuple(x.shape[:-1]) + (dout,) or out.stride(-1) != 1:
+            raise ValueError(f"out: expected shape {tuple(x.shape[:-1]) + (dout,)} with unit inner stride")
+        ldy = out.stride(-2) if out.dim() >= 2 else dout
+        for d in range(out.dim() - 2):   # leading dims must be row-contiguous w.r.t. ldy
+            if out.stride(d) != out.stride(d + 1) * out.shape[d + 1]:
+                raise ValueError("out: leading dimensions must be contiguous")
+    with torch.cuda.device(x.device):
+        check(load().gn_mlp2_f32(_ptr(x), _ptr(pk["W0p"]), _ptr(pk["b0"]), _ptr(pk["W1p"]), _ptr(pk["b1"]), _ptr(out),
+                                 rows, din, dh, dout, ldy, stream_handle()), "gn_mlp2_f32")
+    return out
+
+
+# ---- noise ---------------------------------------------------------------------------------------
+def philox_uniform(shape: Sequence[int], seed: int, offset: int, device) -> Tensor:
+    U = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    if not U.is_cuda:
+        raise ValueError("philox_uniform: device must be a GPU")
+    with torch.cuda.device(U.device):
+        check(load().gn_philox_uniform_f32(_ptr(U), U.numel(), int(seed) & (2**64 - 1), int(offset), stream_handle()),
+              "gn_philox_uniform_f32")
+    return U

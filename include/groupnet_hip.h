@@ -1,0 +1,148 @@
+/*
+ * groupnet_hip.h — C ABI of libgroupnet_hip.so: the MI355X (gfx950) kernels of the
+ * GroupNet MS-HGNN hot path.
+ *
+ * The reference (TaliMotzkin/GroupNet) is pure Python/PyTorch and has no FFI for this
+ * path; each entry point below names the reference lines it replaces (paths relative to
+ * the reference root).  A host binds them with ctypes/cffi/cgo/JNI: plain pointers and
+ * ints only, no torch types.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory owned by the caller, fp32, row-major, contiguous,
+ *     16-byte aligned (torch allocations are); inputs are never written;
+ *   - `stream` is a hipStream_t (NULL = the default stream); launchers enqueue and return,
+ *     they never synchronise, allocate or free — safe to capture in a hipGraph;
+ *   - return value: GN_OK (0) or a negative GN_ERR_* code; nothing is launched on error;
+ *   - B scenes, N agents (nodes), E hyperedges, K edge types, D = 64 feature width.
+ *   - "packed" weights are produced by gn_pack_linear_f32 from an nn.Linear weight
+ *     (out x in, row-major); the layout is private to the library.
+ */
+#ifndef GROUPNET_HIP_H
+#define GROUPNET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gn_stream_t; /* hipStream_t */
+
+#define GN_OK 0
+#define GN_ERR_NULL -1        /* a required pointer is NULL */
+#define GN_ERR_SHAPE -2       /* a size is <= 0 or unsupported (see each function) */
+#define GN_ERR_K_RANGE -3     /* top-k: k > N  (torch.topk raises RuntimeError here) */
+#define GN_ERR_ALIGN -4       /* a pointer is not 16-byte aligned */
+#define GN_ERR_LAUNCH -5      /* hipGetLastError() reported a launch failure */
+#define GN_ERR_LDS -6         /* the problem does not fit the 160 KiB LDS tile of the kernel */
+
+#define GN_FEAT 64            /* h_dim == hdim_extend == 64 (MS_HGNN_batch.py:72,292) */
+#define GN_MAX_TYPES 16       /* edge types K <= 16 (reference: 6 pairwise, 10 hyper) */
+#define GN_MAX_SCALES 8
+
+/* ABI version of this header; bumped on any signature change. */
+int gn_abi_version(void);
+/* Short static description of a GN_ERR_* code. */
+const char* gn_strerror(int code);
+
+/* ---- A0: cosine affinity -------------------------------------------------------------
+ * corr[b] = q q^T with q = f / max(||f||_2, 1e-12) per agent.
+ * Replaces model/GroupNet_nba.py:284-286 (F.normalize + matmul).
+ * f (B,N,D) -> corr (B,N,N).  D must be a multiple of 4, D <= 1024. */
+int gn_affinity_f32(const float* f, float* corr, int B, int N, int D, gn_stream_t stream);
+
+/* ---- A1: top-k hyperedge incidence -----------------------------------------------------
+ * Replaces MS_HGNN_hyper.init_adj_attention, model/MS_HGNN_batch.py:372-388
+ * (torch.topk + zeros().scatter()).  For each of n_scales group sizes k_s:
+ *   k_s == N : H_s is (B,1,N), all ones;
+ *   else     : k = max(k_s,1); H_s is (B,N,N) with H_s[b,i,c] = 1 iff c is among the k
+ *              largest entries of corr[b,i,:]  (ties: lowest index wins; NaN ranks first);
+ *   k_s > N  : GN_ERR_K_RANGE.
+ * H_list / k_list are HOST arrays of n_scales entries (1 <= n_scales <= GN_MAX_SCALES);
+ * one pass over corr serves every scale. */
+int gn_topk_incidence_f32(const float* corr, float* const* H_list, const int* k_list, int n_scales,
+                          int B, int N, gn_stream_t stream);
+
+/* A0+A1 fused: f -> corr (may be NULL: not written) and every H_s, without re-reading corr
+ * from HBM.  Same contracts as the two functions above; N*(N+D)*4 bytes must fit in LDS. */
+int gn_affinity_topk_f32(const float* f, float* corr, float* const* H_list, const int* k_list,
+                         int n_scales, int B, int N, int D, gn_stream_t stream);
+
+/* ---- weight packing -------------------------------------------------------------------
+ * Number of floats of the packed image of an (out x in) nn.Linear weight. */
+size_t gn_packed_elems(int out_features, int in_features);
+/* W (out x in, row-major) -> Wp (gn_packed_elems floats).  The rows/cols are zero-padded to
+ * multiples of 32.  `col_offset`/`ld` let a sub-block of a wider matrix be packed:
+ * element (o,i) is read from W[o*ld + col_offset + i]. */
+int gn_pack_linear_f32(const float* W, float* Wp, int out_features, int in_features, int ld,
+                       int col_offset, gn_stream_t stream);
+
+/* ---- A3 (first half): node MLP + attention projections -----------------------------------
+ * x' = MLP_{64->256->64}(x)            (node2edge_start_mlp, MS_HGNN_batch.py:125,358)
+ * pq = x' Wpq^T + bpq  (64 wide)       the node-side halves of attention_mlp layer 0
+ *                                      (MS_HGNN_batch.py:131-134,362-365), see gn_node2edge_f32.
+ * x (rows,64) -> xp (rows,64), pq (rows,64).  W*: packed, b*: plain (256 / 64 / 64 floats). */
+int gn_node_mlp_f32(const float* x, const float* W0p, const float* b0, const float* W1p,
+                    const float* b1, const float* Wpqp, const float* bpq, float* xp, float* pq,
+                    int rows, gn_stream_t stream);
+
+/* ---- A3 (second half): attention-weighted node -> edge pooling ---------------------------
+ * Replaces the rest of node2edge, MS_HGNN_batch.py:127-141 / 359-370:
+ *   e0 = H x';  att[e,n] = w2 . relu(P_n + (H Qn)_e) + b2  with P = pq[:, :32] (bias folded),
+ *   Qn = pq[:, 32:];  W = softmax_n(att * H) * H;  edges = W x'.
+ * H == NULL selects the pairwise graph of MS_HGNN_oridinary (E = N*N, edge e = i*N + j has
+ * weight 1 on i and on j, 2 when i == j; MS_HGNN_batch.py:118,124,143-160) without ever
+ * materialising it.  xp, pq (B,N,64); H (B,E,N) or NULL; w2 (32 floats, device); b2 scalar
+ * passed by value;  edges (B,E,64). */
+int gn_node2edge_f32(const float* xp, const float* pq, const float* H, const float* w2, float b2,
+                     float* edges, int B, int N, int E, gn_stream_t stream);
+
+/* ---- A4: per-edge MLPs + Gumbel-softmax edge typing ----------------------------------------
+ * Replaces MLP_dict_softmax.forward + gumbel_softmax, MS_HGNN_batch.py:41-53,446-520:
+ *   z = MLP_{64->128->64}(edges); logits = MLP_{64->128->K}(z); fac = sigmoid(MLP_{64->128->1}(z));
+ *   g = -log(1e-10 - log(U + 1e-10)); dist = softmax((logits + g) / tau); edge_feat = fac * dist.
+ * Wd0p packs [MLP_distribution.layers.0 ; MLP_factor.layers.0] (256 x 64), bd0 the 256 biases;
+ * Wd1p packs the (32 x 256) block matrix whose rows 0..K-1 are [MLP_distribution.layers.1, 0]
+ * and row K is [0, MLP_factor.layers.1]; bd1 (32 floats) likewise.
+ * edges (rows,64), U (rows,K) uniforms in [0,1) -> edge_feat (rows,K), dist (rows,K).  K <= 15. */
+int gn_edge_mlp_gumbel_f32(const float* edges, const float* U, const float* Wi0p, const float* bi0,
+                           const float* Wi1p, const float* bi1, const float* Wd0p, const float* bd0,
+                           const float* Wd1p, const float* bd1, float* edge_feat, float* dist,
+                           int rows, int K, float tau, gn_stream_t stream);
+
+/* ---- A5: hyperedge aggregation --------------------------------------------------------------
+ * gather: eo = H ori            (edge_aggregation.forward, MS_HGNN_batch.py:263)
+ * H == NULL: pairwise graph, eo[(i,j)] = ori_i + ori_j.   ori (B,N,64) -> eo (B,E,64). */
+int gn_agg_gather_f32(const float* ori, const float* H, float* eo, int B, int N, int E,
+                      gn_stream_t stream);
+/* typed MLP: feat = sum_k edge_feat[:,k] * MLP^k_{64->128->64}(eo)   (MS_HGNN_batch.py:262,264-265)
+ * W1p: K packed (128 x 64) images back to back, b1 (K,128); W2p: K packed (64 x 128), b2 (K,64).
+ * eo (rows,64), edge_feat (rows,K) -> feat (rows,64). */
+int gn_agg_mlp_f32(const float* eo, const float* edge_feat, const float* W1p, const float* b1,
+                   const float* W2p, const float* b2, float* feat, int rows, int K,
+                   gn_stream_t stream);
+/* scatter: out = cat(H^T feat, ori) / divisor     (MS_HGNN_batch.py:267; divisor = N gives the
+ * division of edge2node :120,355, divisor = 1 the bare edge_aggregation.forward).
+ * feat (B,E,64), ori (B,N,64) -> out (B,N,128).  H == NULL: pairwise. */
+int gn_agg_scatter_f32(const float* feat, const float* H, const float* ori, float* out, int B, int N,
+                       int E, float divisor, gn_stream_t stream);
+
+/* ---- A6 / generic two-layer MLP ---------------------------------------------------------------
+ * y = W1 relu(W0 x + b0) + b1     (MLP.forward with one hidden layer, MS_HGNN_batch.py:220-229;
+ * nmp_mlp_end 128->128->bottleneck and nmp_mlps[even] 128->128->64).
+ * din in {64,128}, dh in {128,256}, dout >= 1 (padded to 32 inside the packed image).
+ * x (rows,din) -> y (rows,dout) with row stride ldy >= dout floats (lets the result land in a
+ * column block of a wider tensor, e.g. the concatenated per-scale features). */
+int gn_mlp2_f32(const float* x, const float* W0p, const float* b0, const float* W1p, const float* b1,
+                float* y, int rows, int din, int dh, int dout, int ldy, gn_stream_t stream);
+
+/* ---- device noise (build's own; the reference draws torch.rand on the host) --------------------
+ * U[i] = Philox4x32-10(counter = (i + offset) / 4, key = seed)[(i + offset) % 4] >> 8, scaled to
+ * [0,1).  Lets a sharded run draw exactly the rows of the full-batch stream it owns. */
+int gn_philox_uniform_f32(float* U, size_t n, unsigned long long seed, unsigned long long offset,
+                          gn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GROUPNET_HIP_H */
