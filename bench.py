@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py — scenes/s of the GroupNet MS-HGNN forward on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W          (N > 1, one rank per GPU)
+
+One "step" = one MS-HGNN forward over one batch of synthetic agent features already resident in
+HBM: cosine affinity + top-k incidence of every scale (one fused launch), the pairwise module and
+one hyper module per scale {2,5,11} (model/GroupNet_nba.py:284-311), Gumbel noise drawn on the
+device inside the step, features written into the concatenated (B, N, 320) tensor; with N > 1 ranks
+each rank owns 512 scenes (BASELINE config 3: 4096 scenes over 8 GPUs — weak scaling) and the step
+ends with ONE all-gather of the output embeddings over RCCL/xGMI.  The step is a captured hipGraph.
+
+Rank 0 prints one JSON line.  Besides the contract fields it carries
+  roofline      the dominant kernel (typed aggregation MLP of the pairwise module, fp32 MFMA):
+                algorithmic FLOPs per launch / its average duration, measured here with HIP events on
+                the stream it is launched on, in an instrumented pass over the same K steps;
+  agg_hbm       the hyperedge aggregation gather+scatter kernels against the HBM roofline at
+                N=11/B=4096 (north_star target >= 30 %), measured the same way;
+  cpu_baseline  the CPU oracle (a port of the reference's PyTorch path) timed on this box's host
+                cores on the same workload — a baseline, not a target.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_AGENTS = 11
+SCALES = [2, 5, 11]
+B_PER_GPU = 512
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak
+
+
+def agg_mlp_flops(rows, K):
+    """Algorithmic FLOPs of feat = sum_k ef_k * (W2k relu(W1k eo + b1k) + b2k) per launch:
+    per row and type 2*(64*128) + 2*(128*64) MAC-flops, + 2*64 for the typed scale-and-add."""
+    return rows * K * (2 * 64 * 128 + 2 * 128 * 64 + 2 * 64)
+
+
+def agg_hbm_bytes(B, N, E):
+    """gather 4(N*D + E*N + E*D) + scatter 4(E*D + E*N + N*D + 2N*D) per scene."""
+    D = 64
+    return B * (4 * (N * D + E * N + E * D) + 4 * (E * D + E * N + N * D + 2 * N * D))
+
+
+class Probe:
+    """Brackets every launch of one kernel (name, K) with HIP events on its own stream."""
+
+    def __init__(self, name, K):
+        self.name, self.K = name, K
+        self.pairs, self._open = [], None
+
+    def __call__(self, name, K, rows, before):
+        if name != self.name or K != self.K:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        if before:
+            self._open = (ev, rows)
+        else:
+            self.pairs.append((self._open[0], ev, self._open[1]))
+
+    def mean_ms(self):
+        return statistics.fmean(a.elapsed_time(b) for a, b, _ in self.pairs)
+
+
+def time_kernel_ms(fn, reps=20, warm=3):
+    """Average duration of the launches `fn` enqueues, with events on the current stream and the
+    host kept ahead of the GPU by a spin kernel."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(2_000_000)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def cpu_baseline(block_state, B, N, threads, budget_s=20.0):
+    """The oracle on the host cores: same workload (B scenes, pairwise + 3 scales), host noise drawn
+    as the reference does.  Bounded sample: as many full forwards as fit in ~budget_s (>= 2)."""
+    from oracle import ms_hgnn_oracle as O
+    torch.set_num_threads(threads)
+    sp, shs = block_state
+    g = torch.Generator().manual_seed(1234)
+    h = torch.randn(B, N, 64, generator=g)
+    times = []
+    with torch.no_grad():
+        t_end = time.time() + budget_s
+        it = 0
+        while it < 2 or (time.time() < t_end and it < 12):
+            t0 = time.perf_counter()
+            Up = [O.draw_uniform(s) for s in O.noise_shapes(B, N, None)]
+            Uh = [[O.draw_uniform(s) for s in O.noise_shapes(B, N, sc)] for sc in SCALES]
+            O.ms_hgnn_multiscale_forward(sp, shs, SCALES, h, Up, Uh, decomposed=False)
+            times.append(time.perf_counter() - t0)
+            it += 1
+    best = statistics.median(times[1:]) if len(times) > 1 else times[0]
+    return dict(value=B / best, unit="scenes/s", cores=threads, kind="port",
+                sample=f"{len(times)} full forwards at B={B}, N={N}, scales {SCALES} (median of all but the first); "
+                       f"torch {torch.__version__} CPU, materialised attention tensor as the reference executes")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch-per-gpu", type=int, default=B_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 through torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: groupnet_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from groupnet_amd import ops
+    from groupnet_amd.graphs import GraphedMultiScale
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    import groupnet_amd as G
+
+    Bl, N = args.batch_per_gpu, N_AGENTS
+    B_total = Bl * world
+    torch.manual_seed(0)                      # same seeded default-init weights on every rank
+    block = MultiScaleHGNN(SCALES)
+    block_state = ({k: v.detach().clone() for k, v in block.interaction.state_dict().items()},
+                   [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in block.interaction_hyper])
+    block.to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    f = torch.randn(Bl, N, 64, generator=g, device=dev)     # synthetic agent embeddings, resident in HBM
+    gathered = torch.empty((B_total, N, block.out_features), device=dev) if world > 1 else None
+
+    with torch.no_grad():
+        if args.no_graph:
+            G.set_noise_mode("device", seed=99)
+            run = lambda: block(f)[0]
+        else:
+            graphed = GraphedMultiScale(block, Bl, N, seed=99)
+            graphed.f_in.copy_(f)
+            run = lambda: graphed()[0]
+
+        def step():
+            out = run()
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, out)
+            return out
+
+        def fence():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # ---- roofline leg: instrumented eager pass over the same K steps (rank 0) -------------------
+        roof = agg = None
+        if rank == 0:
+            G.set_noise_mode("device", seed=99)
+            probe = Probe("agg_mlp", block.interaction.edge_types)
+            ops.launch_probe = probe
+            torch.cuda.synchronize()
+            for _ in range(min(args.steps, 50)):
+                torch.cuda._sleep(1_500_000)        # keep the host ahead: no launch gaps inside the brackets
+                block(f)
+            ops.launch_probe = None
+            torch.cuda.synchronize()
+            ms = probe.mean_ms()
+            rows = probe.pairs[0][2]
+            fl = agg_mlp_flops(rows, block.interaction.edge_types)
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = dict(kernel="agg_mlp_kernel<6> (typed aggregation MLP, pairwise module)", bound="mfma",
+                        achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                        avg_launch_us=round(ms * 1e3, 2), flops_per_launch=fl, rows_per_launch=rows,
+                        launches_timed=len(probe.pairs))
+            # ---- north_star: hyperedge aggregation gather+scatter vs HBM at N=11 / B=4096 ----------------
+            Bb = 4096
+            ori = torch.randn(Bb, N, 64, device=dev)
+            _, Hs = ops.affinity_topk(ori, [5], want_corr=False)
+            H = Hs[0]
+            feat = torch.randn(Bb, N, 64, device=dev)
+            t_g = time_kernel_ms(lambda: ops.agg_gather(ori, H))
+            t_s = time_kernel_ms(lambda: ops.agg_scatter(feat, H, ori))
+            by = agg_hbm_bytes(Bb, N, N)
+            gbs = by / ((t_g + t_s) * 1e-3) / 1e9
+            agg = dict(kernel="agg_gather_kernel + agg_scatter_kernel (hyper, E=N=11, B=4096)", bound="hbm",
+                       achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                       traffic=None, gather_us=round(t_g * 1e3, 2), scatter_us=round(t_s * 1e3, 2),
+                       bytes_per_launch_pair=by)
+            G.set_noise_mode("host")
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = max(1, min(16, len(os.sched_getaffinity(0))))
+        cpu = cpu_baseline(block_state, Bl, N, threads)
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        line = {
+            "metric": "scenes/sec GroupNet MS-HGNN forward, NBA N=11 B=512, 1/2/4/8 MI355X",
+            "value": round(B_total * args.steps / elapsed, 1),
+            "unit": "scenes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"MS-HGNN forward: affinity + top-k + pairwise + hyper scales {SCALES}, "
+                                   f"N={N} agents, {Bl} scenes per GPU (global batch {B_total}), fp32, "
+                                   f"device Philox noise, {'eager' if args.no_graph else 'hipGraph replay'}"
+                                   + (", + all-gather of (B,N,320) embeddings over RCCL" if world > 1 else ""),
+                       "global_batch": B_total, "agents": N, "scales": SCALES,
+                       "parallelism": f"batch-sharded x{world}"},
+            "roofline": roof, "agg_hbm": agg, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,14 +40,18 @@ _GUMBEL_TAU = 0.5      # model/MS_HGNN_batch.py:45
 class _NoiseState:
     mode = "host"   # "host": torch.rand on the CPU generator (reference contract); "device": Philox
     seed = 0
-    offset = 0      # running element offset of the device stream
+    offset = 0      # running element offset of the device stream (host-side bookkeeping)
+    counter = None  # optional 1-element int64 GPU tensor added to `offset` on the device (graph replays)
 
 
-def set_noise_mode(mode: str, seed: Optional[int] = None, offset: int = 0) -> None:
-    """'host' (default, reference-identical stream) or 'device' (Philox4x32-10, no host work)."""
+def set_noise_mode(mode: str, seed: Optional[int] = None, offset: int = 0, counter: Optional[Tensor] = None) -> None:
+    """'host' (default, reference-identical stream) or 'device' (Philox4x32-10, no host work).
+    ``counter``: a 1-element int64 GPU tensor holding the stream position on the DEVICE; a captured
+    hipGraph that ends with ``ops.counter_add(counter, n)`` then draws fresh noise on every replay."""
     if mode not in ("host", "device"):
         raise ValueError("mode must be 'host' or 'device'")
     _NoiseState.mode = mode
+    _NoiseState.counter = counter if mode == "device" else None
     if seed is not None:
         _NoiseState.seed = int(seed)
         _NoiseState.offset = int(offset)
@@ -57,7 +61,7 @@ def _draw_uniform(shape: Tuple[int, int, int], device: torch.device) -> Tensor:
     if _NoiseState.mode == "host":
         return torch.rand(shape).float().to(device, non_blocking=True)
     n = shape[0] * shape[1] * shape[2]
-    u = ops.philox_uniform(shape, _NoiseState.seed, _NoiseState.offset, device)
+    u = ops.philox_uniform(shape, _NoiseState.seed, _NoiseState.offset, device, _NoiseState.counter)
     _NoiseState.offset += n
     return u
 

@@ -41,7 +41,8 @@ SIGNATURES = {
     "gn_agg_mlp_f32": (_I, [_P] * 7 + [_I, _I, _P]),
     "gn_agg_scatter_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "gn_mlp2_f32": (_I, [_P] * 6 + [_I, _I, _I, _I, _I, _P]),
-    "gn_philox_uniform_f32": (_I, [_P, _SZ, _U64, _U64, _P]),
+    "gn_philox_uniform_f32": (_I, [_P, _SZ, _U64, _U64, _P, _P]),
+    "gn_counter_add_u64": (_I, [_P, _U64, _P]),
 }
 
 _lib = None

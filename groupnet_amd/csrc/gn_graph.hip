@@ -417,7 +417,9 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
 
 __global__ __launch_bounds__(kBlock) void philox_uniform_kernel(float* __restrict__ U, unsigned long long n,
                                                                 unsigned long long seed, unsigned long long offset,
+                                                                const unsigned long long* __restrict__ offset_dev,
                                                                 unsigned long long nblk) {
+  if (offset_dev) offset += *offset_dev;   // stream position kept in device memory (graph replays advance it)
   const unsigned long long blk0 = offset >> 2;
   for (unsigned long long t = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; t < nblk;
        t += (unsigned long long)gridDim.x * kBlock) {
@@ -612,12 +614,24 @@ extern "C" int gn_agg_scatter_f32(const float* feat, const float* H, const float
   return gn_check_launch();
 }
 
+__global__ void counter_add_kernel(unsigned long long* ctr, unsigned long long add) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *ctr += add;
+}
+
 extern "C" int gn_philox_uniform_f32(float* U, size_t n, unsigned long long seed, unsigned long long offset,
-                                     gn_stream_t stream) {
+                                     const unsigned long long* offset_dev, gn_stream_t stream) {
   GN_REQUIRE_PTR(U);
   if (n == 0) return GN_ERR_SHAPE;
-  const unsigned long long nblk = ((offset + n + 3) >> 2) - (offset >> 2);
+  // with a device-side base the first block may be partial whatever `offset` is: one spare block
+  const unsigned long long nblk =
+      offset_dev ? (((unsigned long long)n + 3) >> 2) + 1 : ((offset + n + 3) >> 2) - (offset >> 2);
   hipLaunchKernelGGL(philox_uniform_kernel, dim3(capped_grid((long long)nblk, kBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, U, (unsigned long long)n, seed, offset, nblk);
+                     (hipStream_t)stream, U, (unsigned long long)n, seed, offset, offset_dev, nblk);
+  return gn_check_launch();
+}
+
+extern "C" int gn_counter_add_u64(unsigned long long* counter, unsigned long long add, gn_stream_t stream) {
+  GN_REQUIRE_PTR(counter);
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, add);
   return gn_check_launch();
 }

@@ -210,10 +210,14 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(
 }
 
 // ---- A5 typed MLP: feat = sum_k ef[:,k] * (W2k relu(W1k eo + b1k) + b2k) --------------------------
+// KT = number of edge types when known at compile time (6: pairwise module, 10: hyper module — the two
+// get distinct kernel names, which keeps their rocprof rows apart), 0 = runtime K.
+template <int KT>
 __global__ __launch_bounds__(256) void agg_mlp_kernel(const float* __restrict__ eo, const float* __restrict__ ef,
                                                       const float* __restrict__ W1p, const float* __restrict__ b1,
                                                       const float* __restrict__ W2p, const float* __restrict__ b2,
-                                                      float* __restrict__ feat, int rows, int K) {
+                                                      float* __restrict__ feat, int rows, int K_rt) {
+  const int K = KT > 0 ? KT : K_rt;
   const RowBlock rb = row_block(rows);
   if (gn_uniform(rb.row - (rb.lane & 31)) >= rows) return;
   f32x16 in[2], hid[4], out[2];
@@ -350,8 +354,14 @@ extern "C" int gn_agg_mlp_f32(const float* eo, const float* edge_feat, const flo
   const void* al[] = {eo, W1p, b1, W2p, b2, feat};
   for (const void* p : al) GN_REQUIRE_ALIGNED(p);
   if (rows <= 0 || K < 1 || K > GN_MAX_TYPES) return GN_ERR_SHAPE;
-  hipLaunchKernelGGL(agg_mlp_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, eo, edge_feat, W1p, b1,
-                     W2p, b2, feat, rows, K);
+  const dim3 grid(row_grid(rows)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 6)
+    hipLaunchKernelGGL((agg_mlp_kernel<6>), grid, block, 0, s, eo, edge_feat, W1p, b1, W2p, b2, feat, rows, K);
+  else if (K == 10)
+    hipLaunchKernelGGL((agg_mlp_kernel<10>), grid, block, 0, s, eo, edge_feat, W1p, b1, W2p, b2, feat, rows, K);
+  else
+    hipLaunchKernelGGL((agg_mlp_kernel<0>), grid, block, 0, s, eo, edge_feat, W1p, b1, W2p, b2, feat, rows, K);
   return gn_check_launch();
 }
 

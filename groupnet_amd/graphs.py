@@ -1,0 +1,74 @@
+"""hipGraph capture of the multiscale forward.
+
+One MS-HGNN forward is ~35 short kernel launches on 1+S streams; at B=512 the GPU work is a few
+hundred microseconds, less than what the host needs to issue those launches one by one.  The
+launchers of libgroupnet_hip.so never synchronise or allocate, so the whole forward (side-stream
+fork/join included) is captured once into a hipGraph and replayed with one host call.
+
+Noise inside a graph: the host draw of the reference (torch.rand on the CPU) cannot be captured, so
+a graphed forward uses the device Philox stream.  Its position lives in a device counter that the
+graph itself advances at the end of every replay — each replay draws fresh, reproducible noise.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import MS_HGNN_batch as _mods
+from . import ops
+from .multiscale import MultiScaleHGNN
+
+Tensor = torch.Tensor
+
+
+class GraphedMultiScale:
+    """Static-shape, replayable forward of a ``MultiScaleHGNN`` block.
+
+        g = GraphedMultiScale(block, B, N, seed=1234)
+        feats, H = g(f)          # f is copied into the graph's input buffer; outputs are the
+                                 # graph's static buffers (overwritten by the next call)
+    """
+
+    def __init__(self, block: MultiScaleHGNN, B: int, N: int, seed: int = 0, device: Optional[torch.device] = None,
+                 warmup: int = 2):
+        p = next(block.parameters())
+        self.device = device or p.device
+        if self.device.type != "cuda":
+            raise ValueError("GraphedMultiScale needs the block on a GPU")
+        self.block = block
+        self.B, self.N = B, N
+        self.seed = int(seed)
+        self.f_in = torch.zeros((B, N, block.h_dim), dtype=torch.float32, device=self.device)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.draws_per_step = sum(b * e * k for (b, e, k) in block.noise_shapes(B, N)) * block.interaction.nmp_layers
+        self.graph = torch.cuda.CUDAGraph()
+        prev = (_mods._NoiseState.mode, _mods._NoiseState.seed, _mods._NoiseState.offset, _mods._NoiseState.counter)
+        try:
+            with torch.no_grad(), torch.cuda.device(self.device):
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):      # warm-up off the default stream: packs weights, sizes the pool
+                    for _ in range(max(1, warmup)):
+                        self._step()
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                torch.cuda.synchronize(self.device)
+                self.counter.zero_()
+                with torch.cuda.graph(self.graph):
+                    self.out, self.H = self._step()
+        finally:
+            _mods.set_noise_mode(prev[0], prev[1], prev[2], prev[3])
+
+    def _step(self) -> Tuple[Tensor, Optional[Tensor]]:
+        # offset 0 + device counter: the position is entirely on the device
+        _mods.set_noise_mode("device", seed=self.seed, offset=0, counter=self.counter)
+        out, H = self.block(self.f_in)
+        # each module drew from [counter + its host-side offset); move the base past all of them
+        ops.counter_add(self.counter, self.draws_per_step)
+        return out, H
+
+    def __call__(self, f: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+        if f is not None:
+            self.f_in.copy_(f, non_blocking=True)
+        self.graph.replay()
+        return self.out, self.H

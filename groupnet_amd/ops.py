@@ -186,9 +186,14 @@ def agg_mlp(eo: Tensor, edge_feat: Tensor, pk: dict, K: int) -> Tensor:
     _req(edge_feat, "edge_feat", (B, E, K))
     _same_device(eo, edge_feat)
     feat = torch.empty_like(eo)
+    probe = launch_probe
     with torch.cuda.device(eo.device):
+        if probe is not None:
+            probe("agg_mlp", K, B * E, True)
         check(load().gn_agg_mlp_f32(_ptr(eo), _ptr(edge_feat), _ptr(pk["W1p"]), _ptr(pk["b1"]), _ptr(pk["W2p"]),
                                     _ptr(pk["b2"]), _ptr(feat), B * E, K, stream_handle()), "gn_agg_mlp_f32")
+        if probe is not None:
+            probe("agg_mlp", K, B * E, False)
     return feat
 
 
@@ -238,11 +243,29 @@ def mlp2(x: Tensor, pk: dict, out: Optional[Tensor] = None) -> Tensor:
 
 
 # ---- noise ---------------------------------------------------------------------------------------
-def philox_uniform(shape: Sequence[int], seed: int, offset: int, device) -> Tensor:
+def philox_uniform(shape: Sequence[int], seed: int, offset: int, device, offset_dev: Optional[Tensor] = None) -> Tensor:
+    """Uniforms in [0,1) from the Philox4x32-10 stream `seed` at element position
+    `offset` (+ the int64 device counter `offset_dev`, if given)."""
     U = torch.empty(tuple(shape), dtype=torch.float32, device=device)
     if not U.is_cuda:
         raise ValueError("philox_uniform: device must be a GPU")
+    if offset_dev is not None and not (offset_dev.is_cuda and offset_dev.dtype == torch.int64 and offset_dev.numel() == 1):
+        raise ValueError("offset_dev: a 1-element int64 GPU tensor")
     with torch.cuda.device(U.device):
-        check(load().gn_philox_uniform_f32(_ptr(U), U.numel(), int(seed) & (2**64 - 1), int(offset), stream_handle()),
-              "gn_philox_uniform_f32")
+        check(load().gn_philox_uniform_f32(_ptr(U), U.numel(), int(seed) & (2**64 - 1), int(offset), _ptr(offset_dev),
+                                           stream_handle()), "gn_philox_uniform_f32")
     return U
+
+
+def counter_add(counter: Tensor, add: int) -> None:
+    """counter += add, in stream order (counter: 1-element int64 GPU tensor)."""
+    if not (counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1):
+        raise ValueError("counter: a 1-element int64 GPU tensor")
+    with torch.cuda.device(counter.device):
+        check(load().gn_counter_add_u64(_ptr(counter), int(add), stream_handle()), "gn_counter_add_u64")
+
+
+# ---- optional instrumentation ----------------------------------------------------------------------
+# bench.py brackets ONE named launch with HIP events on the stream it is launched on (the roofline
+# leg of the bench contract).  `launch_probe` is None in normal use and costs one comparison.
+launch_probe = None

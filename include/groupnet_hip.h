@@ -138,9 +138,13 @@ int gn_mlp2_f32(const float* x, const float* W0p, const float* b0, const float* 
 
 /* ---- device noise (build's own; the reference draws torch.rand on the host) --------------------
  * U[i] = Philox4x32-10(counter = (i + offset) / 4, key = seed)[(i + offset) % 4] >> 8, scaled to
- * [0,1).  Lets a sharded run draw exactly the rows of the full-batch stream it owns. */
+ * [0,1).  Lets a sharded run draw exactly the rows of the full-batch stream it owns.
+ * offset_dev (may be NULL): a device counter ADDED to `offset` when the kernel runs, so that a
+ * captured hipGraph draws fresh noise on every replay; gn_counter_add_u64 advances it in stream
+ * order. */
 int gn_philox_uniform_f32(float* U, size_t n, unsigned long long seed, unsigned long long offset,
-                          gn_stream_t stream);
+                          const unsigned long long* offset_dev, gn_stream_t stream);
+int gn_counter_add_u64(unsigned long long* counter, unsigned long long add, gn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -390,3 +390,29 @@ def test_multiscale_block_matches_oracle(concurrent):
     assert torch.equal(H.cpu(), Href)
     assert maxerr(out, ref) <= TOL
     assert torch.equal(out[..., :64].cpu(), h)
+
+
+def test_graphed_multiscale_fresh_reproducible_noise():
+    """A captured forward draws from a device-side stream position that the graph advances itself:
+    replay k equals an eager forward at offset k * draws_per_step."""
+    import groupnet_amd as G
+    from groupnet_amd.graphs import GraphedMultiScale
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    torch.manual_seed(4)
+    blk = MultiScaleHGNN([2, 5, 11]).to(dev()).eval()
+    B, N = 16, 11
+    f = torch.randn(B, N, 64, device=dev())
+    g = GraphedMultiScale(blk, B, N, seed=321)
+    o1 = g(f)[0].clone()
+    o2 = g(f)[0].clone()
+    assert not torch.equal(o1, o2)
+    try:
+        with torch.no_grad():
+            G.set_noise_mode("device", seed=321, offset=0)
+            e1 = blk(f)[0]
+            G.set_noise_mode("device", seed=321, offset=g.draws_per_step)
+            e2 = blk(f)[0]
+    finally:
+        G.set_noise_mode("host")
+    assert torch.equal(o1, e1) and torch.equal(o2, e2)
+    assert int(g.counter.item()) == 2 * g.draws_per_step
