@@ -164,11 +164,8 @@ class MLP_dict_softmax(nn.Module):
                 bd1[:K] = d1.bias
                 bd1[K] = f1.bias[0]
                 self._pk = dict(
-                    Wi0p=ops.pack_linear(i0.weight.detach().contiguous()), bi0=i0.bias.detach().clone(),
-                    Wi1p=ops.pack_linear(i1.weight.detach().contiguous()), bi1=i1.bias.detach().clone(),
-                    Wd0p=ops.pack_linear(torch.cat((d0.weight, f0.weight), 0).contiguous()),
-                    bd0=torch.cat((d0.bias, f0.bias), 0).contiguous(),
-                    Wd1p=ops.pack_linear(Wd1), bd1=bd1)
+                    W=ops.pack_stream([i0.weight, i1.weight, torch.cat((d0.weight, f0.weight), 0), Wd1]),
+                    bias=ops.bias_stream([i0.bias, i1.bias, torch.cat((d0.bias, f0.bias), 0), bd1]))
             self._pk_key = key
         return self._pk
 
@@ -205,9 +202,8 @@ class edge_aggregation(nn.Module):
                 l0 = [m.layers[0] for m in self.agg_mlp]
                 l1 = [m.layers[1] for m in self.agg_mlp]
                 self._pk = dict(
-                    W1p=torch.cat([ops.pack_linear(l.weight.detach().contiguous()) for l in l0]),
+                    W=ops.pack_stream([w for a, b in zip(l0, l1) for w in (a.weight, b.weight)]),
                     b1=torch.stack([l.bias.detach() for l in l0]).contiguous(),
-                    W2p=torch.cat([ops.pack_linear(l.weight.detach().contiguous()) for l in l1]),
                     b2=torch.stack([l.bias.detach() for l in l1]).contiguous())
             self._pk_key = key
         return self._pk
@@ -276,9 +272,8 @@ class _MessagePassing(nn.Module):
                 # bias) and the edge half, which by linearity is applied to x' before the H-pooling
                 Wpq = torch.cat((a0.weight[:, :D], a0.weight[:, D:]), 0).contiguous()
                 bpq = torch.cat((a0.bias, torch.zeros_like(a0.bias)), 0).contiguous()
-                pk = dict(W0p=ops.pack_linear(s0.weight.detach().contiguous()), b0=s0.bias.detach().clone(),
-                          W1p=ops.pack_linear(s1.weight.detach().contiguous()), b1=s1.bias.detach().clone(),
-                          Wpqp=ops.pack_linear(Wpq), bpq=bpq,
+                pk = dict(W=ops.pack_stream([s0.weight, s1.weight, Wpq]),
+                          bias=ops.bias_stream([s0.bias, s1.bias, bpq]),
                           w2=a1.weight.detach()[0].contiguous().clone(), b2=float(a1.bias.detach()[0].item()))
             self._pk_n2e[idx] = (key, pk)
             hit = self._pk_n2e[idx]
@@ -290,8 +285,7 @@ class _MessagePassing(nn.Module):
         if hit is None or hit[0] != key:
             with torch.no_grad():
                 l0, l1 = _two_layer(mlp)
-                pk = dict(W0p=ops.pack_linear(l0.weight.detach().contiguous()), b0=l0.bias.detach().clone(),
-                          W1p=ops.pack_linear(l1.weight.detach().contiguous()), b1=l1.bias.detach().clone(),
+                pk = dict(W=ops.pack_stream([l0.weight, l1.weight]), bias=ops.bias_stream([l0.bias, l1.bias]),
                           din=l0.in_features, dh=l0.out_features, dout=l1.out_features)
             self._pk_mlp[id(mlp)] = (key, pk)
             hit = self._pk_mlp[id(mlp)]
@@ -300,7 +294,7 @@ class _MessagePassing(nn.Module):
     # -- stages ----------------------------------------------------------------------------------
     def _node2edge(self, x: Tensor, H: Optional[Tensor], idx: int) -> Tensor:
         pk = self._packed_n2e(idx)
-        xp, pq = ops.node_mlp(x, pk["W0p"], pk["b0"], pk["W1p"], pk["b1"], pk["Wpqp"], pk["bpq"])
+        xp, pq = ops.node_mlp(x, pk)
         return ops.node2edge(xp, pq, H, pk["w2"], pk["b2"])
 
     def _edge2node(self, edge_feat: Tensor, ori: Tensor, H: Optional[Tensor], idx: int) -> Tensor:

@@ -13,7 +13,11 @@
 // layer with no LDS round trip and no lane movement; bias is the initial accumulator and ReLU
 // is a register-wise max.  The only memory traffic is the row block in, the row block out and
 // the weight stream, which gn_pack_linear_f32 has laid out in the order the lanes consume it
-// (one coalesced 1 KiB dwordx4 load per wave feeds four MFMAs).
+// (one coalesced 1 KiB dwordx4 load per wave — a "step" — feeds four MFMAs).  All the weights of a
+// kernel form ONE stream in consumption order, read through a register ring that runs kP steps
+// (32 MFMAs, ~2k cycles) ahead of the matrix pipe, across tile, layer and loop boundaries; biases
+// ride one tile ahead in 16 registers.  A lone wave per SIMD therefore stays MFMA-bound, which is
+// what the small hyper modules (B*N rows = fewer waves than SIMDs) need.
 //
 // fp32 MFMA is an exact k-ordered fmaf chain, so results differ from the reference's MKL
 // GEMMs only by summation order (~1e-7 relative).
@@ -74,32 +78,50 @@ __device__ __forceinline__ void store_rows(float* __restrict__ Y, int ld, int ro
     }
 }
 
-__device__ __forceinline__ void bias_init(const float* __restrict__ bias, int h, f32x16& acc) {
+// The 16 bias values a lane needs for one 32-feature output tile (its accumulator's initial value).
+__device__ __forceinline__ f32x16 load_bias_tile(const float* __restrict__ bias_tile, int h) {
+  f32x16 b;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 8 * q + 4 * h);
-    acc[4 * q + 0] = b[0];
-    acc[4 * q + 1] = b[1];
-    acc[4 * q + 2] = b[2];
-    acc[4 * q + 3] = b[3];
+    const f32x4 v = *reinterpret_cast<const f32x4*>(bias_tile + 8 * q + 4 * h);
+    b[4 * q + 0] = v[0];
+    b[4 * q + 1] = v[1];
+    b[4 * q + 2] = v[2];
+    b[4 * q + 3] = v[3];
   }
+  return b;
 }
 
-// acc += W[o-tile, all IT input tiles] . in        (Wp points at tile (o, 0))
+constexpr int kP = 8;          // ring depth in steps
+constexpr int kStep = 64;      // f32x4 elements per step (one per lane)
+struct WRing {
+  f32x4 s[kP];
+};
+__device__ __forceinline__ void ring_prime(WRing& ring, const f32x4* __restrict__ p) {
+#pragma unroll
+  for (int i = 0; i < kP; ++i) ring.s[i] = p[i * kStep];
+}
+
+// acc += W[tile] . in, the tile being 4*IT consecutive steps at `cur` (this lane's pointer).  On entry
+// the ring holds steps 0..kP-1 of the tile; on exit steps 0..kP-1 of whatever `nxt` points at — the
+// tile consumed next (by default the one that follows in memory).
 template <int IT>
-__device__ __forceinline__ void mma_tile(const float* __restrict__ Wp_o, int lane, const f32x16 (&in)[IT],
-                                         f32x16& acc) {
-  const f32x4* w4 = reinterpret_cast<const f32x4*>(Wp_o) + lane;
+__device__ __forceinline__ void mma_tile(const f32x4* __restrict__ cur, const f32x4* __restrict__ nxt, WRing& ring,
+                                         const f32x16 (&in)[IT], f32x16& acc) {
+  constexpr int S = 4 * IT;
+  static_assert(S % kP == 0, "a tile must be a whole number of ring turns");
 #pragma unroll
-  for (int t = 0; t < IT; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 w = w4[(t * 4 + q) * 64];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], in[t][4 * q + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], in[t][4 * q + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], in[t][4 * q + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], in[t][4 * q + 3], acc, 0, 0, 0);
-    }
+  for (int s = 0; s < S; ++s) {
+    const int t = s >> 2, q = s & 3;
+    const f32x4 w = ring.s[s % kP];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], in[t][4 * q + 0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], in[t][4 * q + 1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], in[t][4 * q + 2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], in[t][4 * q + 3], acc, 0, 0, 0);
+    ring.s[s % kP] = (s + kP < S) ? cur[(s + kP) * kStep] : nxt[(s + kP - S) * kStep];
+    // hipcc otherwise sinks the run-ahead load down to its use and collapses the ring to depth 1-2
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 __device__ __forceinline__ void relu16(f32x16& a) {
@@ -107,16 +129,37 @@ __device__ __forceinline__ void relu16(f32x16& a) {
   for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f);
 }
 
-// out = act(W in + b) for a layer with OT output tiles and IT input tiles
+// State of a wave walking the weight / bias streams of a chain of layers laid out back to back.
+struct Chain {
+  const f32x4* w;     // this lane's pointer to the tile consumed next
+  const float* b;     // bias tile of the tile AFTER the one whose bias sits in `bnext`
+  WRing ring;
+  f32x16 bnext;       // bias of the tile consumed next
+  int lane, h;
+};
+__device__ __forceinline__ void chain_begin(Chain& c, const float* __restrict__ W, const float* __restrict__ bias,
+                                            int lane) {
+  c.lane = lane;
+  c.h = lane >> 5;
+  c.w = reinterpret_cast<const f32x4*>(W) + lane;
+  ring_prime(c.ring, c.w);
+  c.bnext = load_bias_tile(bias, c.h);
+  c.b = bias + 32;
+}
+// out = act(W in + b): OT tiles of 4*IT steps each.  `last` marks the final layer of the kernel: its last
+// tile has nothing after it, so the run-ahead loads are pointed back at valid memory.
 template <int OT, int IT, bool RELU>
-__device__ __forceinline__ void linear(const float* __restrict__ Wp, const float* __restrict__ bias, int lane,
-                                       const f32x16 (&in)[IT], f32x16 (&out)[OT]) {
-  const int h = lane >> 5;
+__device__ __forceinline__ void chain_linear(Chain& c, const f32x16 (&in)[IT], f32x16 (&out)[OT], bool last = false) {
+  constexpr int S = 4 * IT;
 #pragma unroll
   for (int o = 0; o < OT; ++o) {
-    bias_init(bias + 32 * o, h, out[o]);
-    mma_tile<IT>(Wp + (size_t)o * IT * kTileFloats, lane, in, out[o]);
+    const bool tail = last && o == OT - 1;
+    out[o] = c.bnext;
+    c.bnext = load_bias_tile(tail ? c.b - 32 : c.b, c.h);
+    mma_tile<IT>(c.w, tail ? c.w : c.w + S * kStep, c.ring, in, out[o]);
     if (RELU) relu16(out[o]);
+    c.w += S * kStep;
+    c.b += 32;
   }
 }
 
@@ -124,64 +167,75 @@ struct RowBlock {
   int lane, h, row, row_ld;  // row = this lane's row; row_ld = clamped row used for loads
   bool live;
 };
-__device__ __forceinline__ RowBlock row_block(int rows) {
+__device__ __forceinline__ RowBlock row_block(int rows, int block_index) {
   RowBlock rb;
   rb.lane = threadIdx.x & 63;
   rb.h = rb.lane >> 5;
-  const int wave = gn_uniform((int)(threadIdx.x >> 6));
-  rb.row = (blockIdx.x * (blockDim.x >> 6) + wave) * 32 + (rb.lane & 31);
+  rb.row = block_index * 32 + (rb.lane & 31);
   rb.live = rb.row < rows;
   rb.row_ld = rb.live ? rb.row : rows - 1;
   return rb;
 }
+__device__ __forceinline__ int wave_id() { return gn_uniform((int)(threadIdx.x >> 6)); }
 
 // ---- A3 first half: x' = MLP(64->256->64)(x); pq = x' Wpq^T + bpq -----------------------------
-__global__ __launch_bounds__(256) void node_mlp_kernel(const float* __restrict__ x, const float* __restrict__ W0p,
-                                                       const float* __restrict__ b0, const float* __restrict__ W1p,
-                                                       const float* __restrict__ b1, const float* __restrict__ Wpqp,
-                                                       const float* __restrict__ bpq, float* __restrict__ xp,
+// W = [W0 (256x64) | W1 (64x256) | Wpq (64x64)] packed, bias = [b0 | b1 | bpq].
+__global__ __launch_bounds__(256) void node_mlp_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ xp,
                                                        float* __restrict__ pq, int rows) {
-  const RowBlock rb = row_block(rows);
-  if (gn_uniform(rb.row - (rb.lane & 31)) >= rows) return;  // whole wave past the end
+  const int blk = blockIdx.x * 4 + wave_id();
+  if (blk * 32 >= rows) return;  // whole wave past the end
+  const RowBlock rb = row_block(rows, blk);
+  Chain c;
+  chain_begin(c, W, bias, rb.lane);
   f32x16 in[2], hid[8], o1[2], o2[2];
   load_rows<2>(x, GN_FEAT, rb.row_ld, rb.h, in);
-  linear<8, 2, true>(W0p, b0, rb.lane, in, hid);
-  linear<2, 8, false>(W1p, b1, rb.lane, hid, o1);
+  chain_linear<8, 2, true>(c, in, hid);
+  chain_linear<2, 8, false>(c, hid, o1);
   store_rows<2>(xp, GN_FEAT, rb.row, rb.h, rb.live, o1);
-  linear<2, 2, false>(Wpqp, bpq, rb.lane, o1, o2);
+  chain_linear<2, 2, false>(c, o1, o2, true);
   store_rows<2>(pq, GN_FEAT, rb.row, rb.h, rb.live, o2);
 }
 
 // ---- A4: z = MLP(64->128->64); [dist|fac] heads; gumbel softmax; sigmoid ------------------------
-__global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(
-    const float* __restrict__ edges, const float* __restrict__ U, const float* __restrict__ Wi0p,
-    const float* __restrict__ bi0, const float* __restrict__ Wi1p, const float* __restrict__ bi1,
-    const float* __restrict__ Wd0p, const float* __restrict__ bd0, const float* __restrict__ Wd1p,
-    const float* __restrict__ bd1, float* __restrict__ edge_feat, float* __restrict__ dist, int rows, int K,
-    float tau) {
-  const RowBlock rb = row_block(rows);
-  if (gn_uniform(rb.row - (rb.lane & 31)) >= rows) return;
+// W = [Wi0 (128x64) | Wi1 (64x128) | Wd0 (256x64) | Wd1 (32x256)] packed, bias likewise.
+__global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(const float* __restrict__ edges,
+                                                              const float* __restrict__ U,
+                                                              const float* __restrict__ W,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ edge_feat, float* __restrict__ dist,
+                                                              int rows, int K, float tau) {
+  const int blk = blockIdx.x * 4 + wave_id();
+  if (blk * 32 >= rows) return;
+  const RowBlock rb = row_block(rows, blk);
+  Chain c;
+  chain_begin(c, W, bias, rb.lane);
   f32x16 in[2], h1[4], z[2], h2[8], lg[1];
   load_rows<2>(edges, GN_FEAT, rb.row_ld, rb.h, in);
-  linear<4, 2, true>(Wi0p, bi0, rb.lane, in, h1);
-  linear<2, 4, false>(Wi1p, bi1, rb.lane, h1, z);
-  linear<8, 2, true>(Wd0p, bd0, rb.lane, z, h2);
-  linear<1, 8, false>(Wd1p, bd1, rb.lane, h2, lg);
+  // the uniforms of this lane's features are fetched now, far ahead of the epilogue
+  const float* urow = U + (size_t)rb.row_ld * K;
+  float u[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int f = feat_of(r, rb.h);
+    u[r] = f < K ? urow[f] : 0.5f;
+  }
+  chain_linear<4, 2, true>(c, in, h1);
+  chain_linear<2, 4, false>(c, h1, z);
+  chain_linear<8, 2, true>(c, z, h2);
+  chain_linear<1, 8, false>(c, h2, lg, true);
 
   // Epilogue.  Features 0..K-1 of `lg` are the logits of this lane's row, feature K the factor
   // pre-activation; a row's features are split over its two lanes (j, h=0) and (j, h=1).
   const float eps = 1e-10f;  // MS_HGNN_batch.py:446
-  const float* urow = U + (size_t)rb.row_ld * K;
   float y[8], e[8];
   float m = -INFINITY, facv = 0.f;
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int f = feat_of(r, rb.h);
-    const bool valid = f < K;
-    const float u = valid ? urow[f] : 0.5f;
-    const float g = -logf(eps - logf(u + eps));
+    const float g = -logf(eps - logf(u[r] + eps));
     y[r] = (lg[0][r] + g) / tau;
-    if (valid) m = fmaxf(m, y[r]);
+    if (f < K) m = fmaxf(m, y[r]);
     if (f == K) facv = lg[0][r];
   }
   m = fmaxf(m, __shfl_xor(m, 32, GN_WAVE));
@@ -210,70 +264,126 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(
 }
 
 // ---- A5 typed MLP: feat = sum_k ef[:,k] * (W2k relu(W1k eo + b1k) + b2k) --------------------------
+// W = for each type k: [W1k (128x64) | W2k (64x128)] packed (64 steps per type); b1 (K,128); b2 (K,64).
 // KT = number of edge types when known at compile time (6: pairwise module, 10: hyper module — the two
 // get distinct kernel names, which keeps their rocprof rows apart), 0 = runtime K.
-template <int KT>
+// KSPLIT = 1: every wave owns a 32-row block and walks all K types.
+// KSPLIT = 4: the 4 waves of a workgroup share ONE row block, wave w takes types w, w+4, ... and the
+//             partial sums meet in LDS — 4x shorter critical path when there are fewer row blocks
+//             than SIMDs (the hyper modules at B*N rows).
+constexpr int kTypeSteps = 64;
+template <int KT, int KSPLIT>
 __global__ __launch_bounds__(256) void agg_mlp_kernel(const float* __restrict__ eo, const float* __restrict__ ef,
-                                                      const float* __restrict__ W1p, const float* __restrict__ b1,
-                                                      const float* __restrict__ W2p, const float* __restrict__ b2,
-                                                      float* __restrict__ feat, int rows, int K_rt) {
+                                                      const float* __restrict__ W, const float* __restrict__ b1,
+                                                      const float* __restrict__ b2, float* __restrict__ feat,
+                                                      int rows, int K_rt) {
   const int K = KT > 0 ? KT : K_rt;
-  const RowBlock rb = row_block(rows);
-  if (gn_uniform(rb.row - (rb.lane & 31)) >= rows) return;
+  const int wave = wave_id();
+  const int blk = KSPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+  if (KSPLIT == 1 && blk * 32 >= rows) return;
+  const RowBlock rb = row_block(rows, blk);
+  const int lane = rb.lane, h = rb.h;
   f32x16 in[2], hid[4], out[2];
-  load_rows<2>(eo, GN_FEAT, rb.row_ld, rb.h, in);
+  load_rows<2>(eo, GN_FEAT, rb.row_ld, h, in);
 #pragma unroll
   for (int o = 0; o < 2; ++o)
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[o][r] = 0.f;
   const float* efrow = ef + (size_t)rb.row_ld * K;
+  const f32x4* Wl = reinterpret_cast<const f32x4*>(W) + lane;
+
+  int k = KSPLIT == 1 ? 0 : wave;
+  if (k < K) {
+    WRing ring;
+    ring_prime(ring, Wl + (size_t)k * kTypeSteps * kStep);
+    f32x16 bnext = load_bias_tile(b1 + k * 128, h);
+    float efk = efrow[k];
+    // b2k as an MFMA A fragment: lane (i, h=0) carries b2k[32o + i]; paired with B = ef_k on k-index 0
+    float b2f0 = h == 0 ? b2[k * 64 + (lane & 31)] : 0.f;
+    float b2f1 = h == 0 ? b2[k * 64 + 32 + (lane & 31)] : 0.f;
 #pragma unroll 1
-  for (int k = 0; k < K; ++k) {
-    const float w = efrow[k];
-    linear<4, 2, true>(W1p + (size_t)k * 8 * kTileFloats, b1 + k * 128, rb.lane, in, hid);
+    while (k < K) {
+      const int kn = k + KSPLIT;
+      const int kc = kn < K ? kn : k;  // what the run-ahead loads target (valid memory either way)
+      const f32x4* base = Wl + (size_t)k * kTypeSteps * kStep;
+      const f32x4* base_next = Wl + (size_t)kc * kTypeSteps * kStep;
+      const float efk_next = efrow[kc];
+      const float b2n0 = h == 0 ? b2[kc * 64 + (lane & 31)] : 0.f;
+      const float b2n1 = h == 0 ? b2[kc * 64 + 32 + (lane & 31)] : 0.f;
+      // layer 1: 4 tiles of 8 steps
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int o = 0; o < 4; ++o) {
+        hid[o] = bnext;
+        bnext = load_bias_tile(o < 3 ? b1 + k * 128 + 32 * (o + 1) : b1 + kc * 128, h);
+        mma_tile<2>(base + o * 8 * kStep, base + (o + 1) * 8 * kStep, ring, in, hid[o]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hid[t][r] *= w;
-    const float* W2k = W2p + (size_t)k * 8 * kTileFloats;
+        for (int r = 0; r < 16; ++r) hid[o][r] = fmaxf(hid[o][r], 0.f) * efk;
+      }
+      // layer 2: 2 tiles of 16 steps, accumulated over types
+      const float efb = h == 0 ? efk : 0.f;
+      out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f0, efb, out[0], 0, 0, 0);
+      mma_tile<4>(base + 32 * kStep, base + 48 * kStep, ring, hid, out[0]);
+      out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f1, efb, out[1], 0, 0, 0);
+      mma_tile<4>(base + 48 * kStep, base_next, ring, hid, out[1]);
+      efk = efk_next;
+      b2f0 = b2n0;
+      b2f1 = b2n1;
+      k = kn;
+    }
+  }
+  if constexpr (KSPLIT == 1) {
+    store_rows<2>(feat, GN_FEAT, rb.row, h, rb.live, out);
+  } else {
+    static_assert(KSPLIT == 4, "the LDS reduction is written for 4 waves");
+    // partial sums of the 4 waves meet in LDS: [wave][register 0..31][lane]
+    __shared__ float part[4][32][64];
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      mma_tile<4>(W2k + (size_t)o * 4 * kTileFloats, rb.lane, hid, out[o]);
-      // + ef_k * b2k
+    for (int o = 0; o < 2; ++o)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + k * 64 + 32 * o + 8 * q + 4 * rb.h);
-        out[o][4 * q + 0] = fmaf(w, b[0], out[o][4 * q + 0]);
-        out[o][4 * q + 1] = fmaf(w, b[1], out[o][4 * q + 1]);
-        out[o][4 * q + 2] = fmaf(w, b[2], out[o][4 * q + 2]);
-        out[o][4 * q + 3] = fmaf(w, b[3], out[o][4 * q + 3]);
+      for (int r = 0; r < 16; ++r) part[wave][16 * o + r][lane] = out[o][r];
+    __syncthreads();
+    // wave w finishes registers 8w .. 8w+7  (tile o = w >> 1, q = 2*(w&1) and 2*(w&1)+1)
+    if (rb.live) {
+      float* p = feat + (size_t)rb.row * GN_FEAT + 4 * h;
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        f32x4 v;
+#pragma unroll
+        for (int cidx = 0; cidx < 4; ++cidx) {
+          const int reg = 8 * wave + 4 * qq + cidx;
+          v[cidx] = (part[0][reg][lane] + part[1][reg][lane]) + (part[2][reg][lane] + part[3][reg][lane]);
+        }
+        const int o = wave >> 1, q = 2 * (wave & 1) + qq;
+        *reinterpret_cast<f32x4*>(p + 32 * o + 8 * q) = v;
       }
     }
   }
-  store_rows<2>(feat, GN_FEAT, rb.row, rb.h, rb.live, out);
 }
 
 // ---- A6 / generic: y = W1 relu(W0 x + b0) + b1, output tiles streamed -----------------------------
+// W = [W0 (dh x din) | W1 (dout x dh)] packed; bias = [b0 (dh) | b1 padded to a multiple of 32].
 template <int IT, int HT>
-__global__ __launch_bounds__(256) void mlp2_kernel(const float* __restrict__ x, const float* __restrict__ W0p,
-                                                   const float* __restrict__ b0, const float* __restrict__ W1p,
-                                                   const float* __restrict__ b1, float* __restrict__ y, int rows,
+__global__ __launch_bounds__(256) void mlp2_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                   const float* __restrict__ bias, float* __restrict__ y, int rows,
                                                    int dout, int ldy) {
-  const RowBlock rb = row_block(rows);
-  if (gn_uniform(rb.row - (rb.lane & 31)) >= rows) return;
+  const int blk = blockIdx.x * 4 + wave_id();
+  if (blk * 32 >= rows) return;
+  const RowBlock rb = row_block(rows, blk);
+  Chain c;
+  chain_begin(c, W, bias, rb.lane);
   f32x16 in[IT], hid[HT];
   load_rows<IT>(x, IT * 32, rb.row_ld, rb.h, in);
-  linear<HT, IT, true>(W0p, b0, rb.lane, in, hid);
+  chain_linear<HT, IT, true>(c, in, hid);
   const int OT = (dout + 31) >> 5;
+  constexpr int S = 4 * HT;
 #pragma unroll 1
   for (int o = 0; o < OT; ++o) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = 32 * o + feat_of(r, rb.h);
-      acc[r] = f < dout ? b1[f] : 0.f;
-    }
-    mma_tile<HT>(W1p + (size_t)o * HT * kTileFloats, rb.lane, hid, acc);
+    const bool tail = o == OT - 1;
+    f32x16 acc = c.bnext;
+    c.bnext = load_bias_tile(tail ? c.b - 32 : c.b, rb.h);
+    mma_tile<HT>(c.w, tail ? c.w : c.w + S * kStep, c.ring, hid, acc);
+    c.w += S * kStep;
+    c.b += 32;
     if (rb.live) {
       float* p = y + (size_t)rb.row * ldy;
       if (((dout | ldy) & 3) == 0) {
@@ -319,69 +429,80 @@ extern "C" int gn_pack_linear_f32(const float* W, float* Wp, int out_features, i
   return gn_check_launch();
 }
 
-extern "C" int gn_node_mlp_f32(const float* x, const float* W0p, const float* b0, const float* W1p, const float* b1,
-                               const float* Wpqp, const float* bpq, float* xp, float* pq, int rows,
+extern "C" int gn_node_mlp_f32(const float* x, const float* W, const float* bias, float* xp, float* pq, int rows,
                                gn_stream_t stream) {
-  const void* ptrs[] = {x, W0p, b0, W1p, b1, Wpqp, bpq, xp, pq};
+  const void* ptrs[] = {x, W, bias, xp, pq};
   for (const void* p : ptrs) {
     GN_REQUIRE_PTR(p);
     GN_REQUIRE_ALIGNED(p);
   }
   if (rows <= 0) return GN_ERR_SHAPE;
-  hipLaunchKernelGGL(node_mlp_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, W0p, b0, W1p, b1,
-                     Wpqp, bpq, xp, pq, rows);
+  hipLaunchKernelGGL(node_mlp_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, W, bias, xp, pq,
+                     rows);
   return gn_check_launch();
 }
 
-extern "C" int gn_edge_mlp_gumbel_f32(const float* edges, const float* U, const float* Wi0p, const float* bi0,
-                                      const float* Wi1p, const float* bi1, const float* Wd0p, const float* bd0,
-                                      const float* Wd1p, const float* bd1, float* edge_feat, float* dist, int rows,
-                                      int K, float tau, gn_stream_t stream) {
-  const void* ptrs[] = {edges, U, Wi0p, bi0, Wi1p, bi1, Wd0p, bd0, Wd1p, bd1, edge_feat, dist};
+extern "C" int gn_edge_mlp_gumbel_f32(const float* edges, const float* U, const float* W, const float* bias,
+                                      float* edge_feat, float* dist, int rows, int K, float tau,
+                                      gn_stream_t stream) {
+  const void* ptrs[] = {edges, U, W, bias, edge_feat, dist};
   for (const void* p : ptrs) GN_REQUIRE_PTR(p);
-  const void* al[] = {edges, Wi0p, bi0, Wi1p, bi1, Wd0p, bd0, Wd1p, bd1};
+  const void* al[] = {edges, W, bias};
   for (const void* p : al) GN_REQUIRE_ALIGNED(p);
   if (rows <= 0 || K < 1 || K > 15 || !(tau > 0.f)) return GN_ERR_SHAPE;
-  hipLaunchKernelGGL(edge_mlp_gumbel_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, edges, U, Wi0p,
-                     bi0, Wi1p, bi1, Wd0p, bd0, Wd1p, bd1, edge_feat, dist, rows, K, tau);
+  hipLaunchKernelGGL(edge_mlp_gumbel_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, edges, U, W,
+                     bias, edge_feat, dist, rows, K, tau);
   return gn_check_launch();
 }
 
-extern "C" int gn_agg_mlp_f32(const float* eo, const float* edge_feat, const float* W1p, const float* b1,
-                              const float* W2p, const float* b2, float* feat, int rows, int K, gn_stream_t stream) {
-  const void* ptrs[] = {eo, edge_feat, W1p, b1, W2p, b2, feat};
+extern "C" int gn_agg_mlp_f32(const float* eo, const float* edge_feat, const float* W, const float* b1,
+                              const float* b2, float* feat, int rows, int K, gn_stream_t stream) {
+  const void* ptrs[] = {eo, edge_feat, W, b1, b2, feat};
   for (const void* p : ptrs) GN_REQUIRE_PTR(p);
-  const void* al[] = {eo, W1p, b1, W2p, b2, feat};
+  const void* al[] = {eo, W, b1, feat};
   for (const void* p : al) GN_REQUIRE_ALIGNED(p);
   if (rows <= 0 || K < 1 || K > GN_MAX_TYPES) return GN_ERR_SHAPE;
-  const dim3 grid(row_grid(rows)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (K == 6)
-    hipLaunchKernelGGL((agg_mlp_kernel<6>), grid, block, 0, s, eo, edge_feat, W1p, b1, W2p, b2, feat, rows, K);
-  else if (K == 10)
-    hipLaunchKernelGGL((agg_mlp_kernel<10>), grid, block, 0, s, eo, edge_feat, W1p, b1, W2p, b2, feat, rows, K);
-  else
-    hipLaunchKernelGGL((agg_mlp_kernel<0>), grid, block, 0, s, eo, edge_feat, W1p, b1, W2p, b2, feat, rows, K);
+  const int blocks32 = (rows + 31) / 32;
+  const dim3 block(256);
+  // fewer row blocks than half the chip's 1024 SIMDs: split the types over the waves of a workgroup
+  if (blocks32 <= 512 && K >= 4) {
+    const dim3 grid(blocks32);
+    if (K == 6)
+      hipLaunchKernelGGL((agg_mlp_kernel<6, 4>), grid, block, 0, s, eo, edge_feat, W, b1, b2, feat, rows, K);
+    else if (K == 10)
+      hipLaunchKernelGGL((agg_mlp_kernel<10, 4>), grid, block, 0, s, eo, edge_feat, W, b1, b2, feat, rows, K);
+    else
+      hipLaunchKernelGGL((agg_mlp_kernel<0, 4>), grid, block, 0, s, eo, edge_feat, W, b1, b2, feat, rows, K);
+  } else {
+    const dim3 grid(row_grid(rows));
+    if (K == 6)
+      hipLaunchKernelGGL((agg_mlp_kernel<6, 1>), grid, block, 0, s, eo, edge_feat, W, b1, b2, feat, rows, K);
+    else if (K == 10)
+      hipLaunchKernelGGL((agg_mlp_kernel<10, 1>), grid, block, 0, s, eo, edge_feat, W, b1, b2, feat, rows, K);
+    else
+      hipLaunchKernelGGL((agg_mlp_kernel<0, 1>), grid, block, 0, s, eo, edge_feat, W, b1, b2, feat, rows, K);
+  }
   return gn_check_launch();
 }
 
-extern "C" int gn_mlp2_f32(const float* x, const float* W0p, const float* b0, const float* W1p, const float* b1,
-                           float* y, int rows, int din, int dh, int dout, int ldy, gn_stream_t stream) {
-  const void* ptrs[] = {x, W0p, b0, W1p, b1, y};
+extern "C" int gn_mlp2_f32(const float* x, const float* W, const float* bias, float* y, int rows, int din, int dh,
+                           int dout, int ldy, gn_stream_t stream) {
+  const void* ptrs[] = {x, W, bias, y};
   for (const void* p : ptrs) GN_REQUIRE_PTR(p);
-  const void* al[] = {x, W0p, b0, W1p, y};
+  const void* al[] = {x, W, bias};
   for (const void* p : al) GN_REQUIRE_ALIGNED(p);
   if (rows <= 0 || dout <= 0 || ldy < dout) return GN_ERR_SHAPE;
   const dim3 grid(row_grid(rows)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (din == 64 && dh == 128)
-    hipLaunchKernelGGL((mlp2_kernel<2, 4>), grid, block, 0, s, x, W0p, b0, W1p, b1, y, rows, dout, ldy);
+    hipLaunchKernelGGL((mlp2_kernel<2, 4>), grid, block, 0, s, x, W, bias, y, rows, dout, ldy);
   else if (din == 64 && dh == 256)
-    hipLaunchKernelGGL((mlp2_kernel<2, 8>), grid, block, 0, s, x, W0p, b0, W1p, b1, y, rows, dout, ldy);
+    hipLaunchKernelGGL((mlp2_kernel<2, 8>), grid, block, 0, s, x, W, bias, y, rows, dout, ldy);
   else if (din == 128 && dh == 128)
-    hipLaunchKernelGGL((mlp2_kernel<4, 4>), grid, block, 0, s, x, W0p, b0, W1p, b1, y, rows, dout, ldy);
+    hipLaunchKernelGGL((mlp2_kernel<4, 4>), grid, block, 0, s, x, W, bias, y, rows, dout, ldy);
   else if (din == 128 && dh == 256)
-    hipLaunchKernelGGL((mlp2_kernel<4, 8>), grid, block, 0, s, x, W0p, b0, W1p, b1, y, rows, dout, ldy);
+    hipLaunchKernelGGL((mlp2_kernel<4, 8>), grid, block, 0, s, x, W, bias, y, rows, dout, ldy);
   else
     return GN_ERR_SHAPE;
   return gn_check_launch();

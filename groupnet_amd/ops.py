@@ -118,14 +118,31 @@ def pack_linear(W: Tensor, col_offset: int = 0, in_features: Optional[int] = Non
 
 
 # ---- A3 ------------------------------------------------------------------------------------------
-def node_mlp(x: Tensor, W0p, b0, W1p, b1, Wpqp, bpq) -> Tuple[Tensor, Tensor]:
+def pack_stream(weights: Sequence[Tensor]) -> Tensor:
+    """One weight stream: the packed images of `weights` (nn.Linear layout, out x in) back to back, in
+    the order a kernel consumes them."""
+    return torch.cat([pack_linear(w.detach().contiguous()) for w in weights])
+
+
+def bias_stream(biases: Sequence[Tensor]) -> Tensor:
+    """Biases back to back, each zero-padded to a multiple of 32 (one 32-float tile per output tile)."""
+    parts = []
+    for b in biases:
+        b = b.detach().reshape(-1)
+        pad = (-b.numel()) % 32
+        parts.append(torch.cat((b, b.new_zeros(pad))) if pad else b)
+    return torch.cat(parts).contiguous()
+
+
+def node_mlp(x: Tensor, pk: dict) -> Tuple[Tensor, Tensor]:
+    """x (B,N,64) -> x' = MLP_{64->256->64}(x), pq = x' Wpq^T + bpq.  pk: {"W": stream, "bias": stream}."""
     _req(x, "x", (None, None, FEAT))
     rows = x.shape[0] * x.shape[1]
     xp = torch.empty_like(x)
     pq = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        check(load().gn_node_mlp_f32(_ptr(x), _ptr(W0p), _ptr(b0), _ptr(W1p), _ptr(b1), _ptr(Wpqp), _ptr(bpq),
-                                     _ptr(xp), _ptr(pq), rows, stream_handle()), "gn_node_mlp_f32")
+        check(load().gn_node_mlp_f32(_ptr(x), _ptr(pk["W"]), _ptr(pk["bias"]), _ptr(xp), _ptr(pq), rows,
+                                     stream_handle()), "gn_node_mlp_f32")
     return xp, pq
 
 
@@ -157,10 +174,9 @@ def edge_mlp_gumbel(edges: Tensor, U: Tensor, pk: dict, K: int, tau: float = 0.5
     edge_feat = torch.empty((B, E, K), dtype=edges.dtype, device=edges.device)
     dist = torch.empty_like(edge_feat)
     with torch.cuda.device(edges.device):
-        check(load().gn_edge_mlp_gumbel_f32(_ptr(edges), _ptr(U), _ptr(pk["Wi0p"]), _ptr(pk["bi0"]), _ptr(pk["Wi1p"]),
-                                            _ptr(pk["bi1"]), _ptr(pk["Wd0p"]), _ptr(pk["bd0"]), _ptr(pk["Wd1p"]),
-                                            _ptr(pk["bd1"]), _ptr(edge_feat), _ptr(dist), B * E, K, float(tau),
-                                            stream_handle()), "gn_edge_mlp_gumbel_f32")
+        check(load().gn_edge_mlp_gumbel_f32(_ptr(edges), _ptr(U), _ptr(pk["W"]), _ptr(pk["bias"]), _ptr(edge_feat),
+                                            _ptr(dist), B * E, K, float(tau), stream_handle()),
+              "gn_edge_mlp_gumbel_f32")
     return edge_feat, dist
 
 
@@ -190,8 +206,8 @@ def agg_mlp(eo: Tensor, edge_feat: Tensor, pk: dict, K: int) -> Tensor:
     with torch.cuda.device(eo.device):
         if probe is not None:
             probe("agg_mlp", K, B * E, True)
-        check(load().gn_agg_mlp_f32(_ptr(eo), _ptr(edge_feat), _ptr(pk["W1p"]), _ptr(pk["b1"]), _ptr(pk["W2p"]),
-                                    _ptr(pk["b2"]), _ptr(feat), B * E, K, stream_handle()), "gn_agg_mlp_f32")
+        check(load().gn_agg_mlp_f32(_ptr(eo), _ptr(edge_feat), _ptr(pk["W"]), _ptr(pk["b1"]), _ptr(pk["b2"]),
+                                    _ptr(feat), B * E, K, stream_handle()), "gn_agg_mlp_f32")
         if probe is not None:
             probe("agg_mlp", K, B * E, False)
     return feat
@@ -237,8 +253,8 @@ def mlp2(x: Tensor, pk: dict, out: Optional[Tensor] = None) -> Tensor:
             if out.stride(d) != out.stride(d + 1) * out.shape[d + 1]:
                 raise ValueError("out: leading dimensions must be contiguous")
     with torch.cuda.device(x.device):
-        check(load().gn_mlp2_f32(_ptr(x), _ptr(pk["W0p"]), _ptr(pk["b0"]), _ptr(pk["W1p"]), _ptr(pk["b1"]), _ptr(out),
-                                 rows, din, dh, dout, ldy, stream_handle()), "gn_mlp2_f32")
+        check(load().gn_mlp2_f32(_ptr(x), _ptr(pk["W"]), _ptr(pk["bias"]), _ptr(out), rows, din, dh, dout, ldy,
+                                 stream_handle()), "gn_mlp2_f32")
     return out
 
 

@@ -15,7 +15,8 @@
  *   - return value: GN_OK (0) or a negative GN_ERR_* code; nothing is launched on error;
  *   - B scenes, N agents (nodes), E hyperedges, K edge types, D = 64 feature width.
  *   - "packed" weights are produced by gn_pack_linear_f32 from an nn.Linear weight
- *     (out x in, row-major); the layout is private to the library.
+ *     (out x in, row-major); the layout is private to the library.  A kernel that applies several
+ *     layers takes ONE buffer holding their packed images back to back, in the order stated.
  */
 #ifndef GROUPNET_HIP_H
 #define GROUPNET_HIP_H
@@ -81,10 +82,11 @@ int gn_pack_linear_f32(const float* W, float* Wp, int out_features, int in_featu
  * x' = MLP_{64->256->64}(x)            (node2edge_start_mlp, MS_HGNN_batch.py:125,358)
  * pq = x' Wpq^T + bpq  (64 wide)       the node-side halves of attention_mlp layer 0
  *                                      (MS_HGNN_batch.py:131-134,362-365), see gn_node2edge_f32.
- * x (rows,64) -> xp (rows,64), pq (rows,64).  W*: packed, b*: plain (256 / 64 / 64 floats). */
-int gn_node_mlp_f32(const float* x, const float* W0p, const float* b0, const float* W1p,
-                    const float* b1, const float* Wpqp, const float* bpq, float* xp, float* pq,
-                    int rows, gn_stream_t stream);
+ * W    = packed images [W0 (256x64) | W1 (64x256) | Wpq (64x64)] back to back (one weight stream,
+ *        consumed in this order); bias = [b0 (256) | b1 (64) | bpq (64)].
+ * x (rows,64) -> xp (rows,64), pq (rows,64). */
+int gn_node_mlp_f32(const float* x, const float* W, const float* bias, float* xp, float* pq, int rows,
+                    gn_stream_t stream);
 
 /* ---- A3 (second half): attention-weighted node -> edge pooling ---------------------------
  * Replaces the rest of node2edge, MS_HGNN_batch.py:127-141 / 359-370:
@@ -101,14 +103,13 @@ int gn_node2edge_f32(const float* xp, const float* pq, const float* H, const flo
  * Replaces MLP_dict_softmax.forward + gumbel_softmax, MS_HGNN_batch.py:41-53,446-520:
  *   z = MLP_{64->128->64}(edges); logits = MLP_{64->128->K}(z); fac = sigmoid(MLP_{64->128->1}(z));
  *   g = -log(1e-10 - log(U + 1e-10)); dist = softmax((logits + g) / tau); edge_feat = fac * dist.
- * Wd0p packs [MLP_distribution.layers.0 ; MLP_factor.layers.0] (256 x 64), bd0 the 256 biases;
- * Wd1p packs the (32 x 256) block matrix whose rows 0..K-1 are [MLP_distribution.layers.1, 0]
- * and row K is [0, MLP_factor.layers.1]; bd1 (32 floats) likewise.
+ * W = packed [init_MLP.0 (128x64) | init_MLP.1 (64x128) | Wd0 (256x64) | Wd1 (32x256)] where
+ *   Wd0 = [MLP_distribution.layers.0 ; MLP_factor.layers.0] and Wd1 is the block matrix whose rows
+ *   0..K-1 are [MLP_distribution.layers.1, 0] and row K is [0, MLP_factor.layers.1];
+ * bias = [128 | 64 | 256 | 32] in the same order (bd1: K logits biases, then the factor bias, zeros).
  * edges (rows,64), U (rows,K) uniforms in [0,1) -> edge_feat (rows,K), dist (rows,K).  K <= 15. */
-int gn_edge_mlp_gumbel_f32(const float* edges, const float* U, const float* Wi0p, const float* bi0,
-                           const float* Wi1p, const float* bi1, const float* Wd0p, const float* bd0,
-                           const float* Wd1p, const float* bd1, float* edge_feat, float* dist,
-                           int rows, int K, float tau, gn_stream_t stream);
+int gn_edge_mlp_gumbel_f32(const float* edges, const float* U, const float* W, const float* bias,
+                           float* edge_feat, float* dist, int rows, int K, float tau, gn_stream_t stream);
 
 /* ---- A5: hyperedge aggregation --------------------------------------------------------------
  * gather: eo = H ori            (edge_aggregation.forward, MS_HGNN_batch.py:263)
@@ -116,11 +117,10 @@ int gn_edge_mlp_gumbel_f32(const float* edges, const float* U, const float* Wi0p
 int gn_agg_gather_f32(const float* ori, const float* H, float* eo, int B, int N, int E,
                       gn_stream_t stream);
 /* typed MLP: feat = sum_k edge_feat[:,k] * MLP^k_{64->128->64}(eo)   (MS_HGNN_batch.py:262,264-265)
- * W1p: K packed (128 x 64) images back to back, b1 (K,128); W2p: K packed (64 x 128), b2 (K,64).
- * eo (rows,64), edge_feat (rows,K) -> feat (rows,64). */
-int gn_agg_mlp_f32(const float* eo, const float* edge_feat, const float* W1p, const float* b1,
-                   const float* W2p, const float* b2, float* feat, int rows, int K,
-                   gn_stream_t stream);
+ * W: for each type k the packed images [agg_mlp[k].layers.0 (128x64) | agg_mlp[k].layers.1 (64x128)],
+ * types back to back; b1 (K,128); b2 (K,64).  eo (rows,64), edge_feat (rows,K) -> feat (rows,64). */
+int gn_agg_mlp_f32(const float* eo, const float* edge_feat, const float* W, const float* b1,
+                   const float* b2, float* feat, int rows, int K, gn_stream_t stream);
 /* scatter: out = cat(H^T feat, ori) / divisor     (MS_HGNN_batch.py:267; divisor = N gives the
  * division of edge2node :120,355, divisor = 1 the bare edge_aggregation.forward).
  * feat (B,E,64), ori (B,N,64) -> out (B,N,128).  H == NULL: pairwise. */
@@ -130,11 +130,12 @@ int gn_agg_scatter_f32(const float* feat, const float* H, const float* ori, floa
 /* ---- A6 / generic two-layer MLP ---------------------------------------------------------------
  * y = W1 relu(W0 x + b0) + b1     (MLP.forward with one hidden layer, MS_HGNN_batch.py:220-229;
  * nmp_mlp_end 128->128->bottleneck and nmp_mlps[even] 128->128->64).
- * din in {64,128}, dh in {128,256}, dout >= 1 (padded to 32 inside the packed image).
+ * din in {64,128}, dh in {128,256}, dout >= 1.  W = packed [W0 (dh x din) | W1 (dout x dh)];
+ * bias = [b0 (dh) | b1 zero-padded to a multiple of 32].
  * x (rows,din) -> y (rows,dout) with row stride ldy >= dout floats (lets the result land in a
  * column block of a wider tensor, e.g. the concatenated per-scale features). */
-int gn_mlp2_f32(const float* x, const float* W0p, const float* b0, const float* W1p, const float* b1,
-                float* y, int rows, int din, int dh, int dout, int ldy, gn_stream_t stream);
+int gn_mlp2_f32(const float* x, const float* W, const float* bias, float* y, int rows, int din, int dh,
+                int dout, int ldy, gn_stream_t stream);
 
 /* ---- device noise (build's own; the reference draws torch.rand on the host) --------------------
  * U[i] = Philox4x32-10(counter = (i + offset) / 4, key = seed)[(i + offset) % 4] >> 8, scaled to

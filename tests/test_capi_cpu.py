@@ -44,8 +44,8 @@ def test_null_and_shape_errors_do_not_launch():
     Hs = (P * 1)(16)
     ks = (ctypes.c_int * 1)(12)
     assert lib.gn_topk_incidence_f32(P(16), Hs, ks, 1, 2, 11, P(0)) == -3      # k > N
-    assert lib.gn_mlp2_f32(P(16), P(16), P(16), P(16), P(16), P(16), 5, 96, 128, 64, 64, P(0)) == -2
-    assert lib.gn_agg_mlp_f32(P(16), P(16), P(16), P(16), P(16), P(16), P(16), 5, 17, P(0)) == -2
+    assert lib.gn_mlp2_f32(P(16), P(16), P(16), P(16), 5, 96, 128, 64, 64, P(0)) == -2
+    assert lib.gn_agg_mlp_f32(P(16), P(16), P(16), P(16), P(16), P(16), 5, 17, P(0)) == -2
     assert lib.gn_node2edge_f32(P(16), P(16), P(0), P(16), 0.0, P(16), 2, 3, 8, P(0)) == -2  # pairwise needs E == N*N
 
 

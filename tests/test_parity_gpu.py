@@ -90,7 +90,7 @@ def test_each_kernel_against_reference_intermediates(name):
         todo += [(f"hyper{s}", hyper, H) for s, H in zip(scales, Hs)]
         for tag, mod, H in todo:
             pk = mod._packed_n2e(0)
-            xp, pq = ops.node_mlp(h, pk["W0p"], pk["b0"], pk["W1p"], pk["b1"], pk["Wpqp"], pk["bpq"])
+            xp, pq = ops.node_mlp(h, pk)
             assert maxerr(xp, c[f"{tag}_xp"]) <= TOL, tag
             edges = ops.node2edge(to_dev(c[f"{tag}_xp"]), pq, H, pk["w2"], pk["b2"])
             assert maxerr(edges, c[f"{tag}_edges"]) <= TOL, tag
@@ -182,7 +182,7 @@ def test_general_incidence_values_and_dense_rows():
     H[1, 1] = 1.0   # a full one
     edges_o, xp_o = O.node2edge(sh, h, H, 0, decomposed=True)
     pk = hyper._packed_n2e(0)
-    xp, pq = ops.node_mlp(h.to(dev()), pk["W0p"], pk["b0"], pk["W1p"], pk["b1"], pk["Wpqp"], pk["bpq"])
+    xp, pq = ops.node_mlp(h.to(dev()), pk)
     edges = ops.node2edge(xp, pq, H.to(dev()), pk["w2"], pk["b2"])
     assert maxerr(xp, xp_o) <= TOL and maxerr(edges, edges_o) <= TOL
     assert maxerr(ops.agg_gather(h.to(dev()), H.to(dev())), O.aggregate_gather(H, h)) <= TOL
@@ -241,8 +241,8 @@ def test_mlp2_shapes_and_pack():
         with torch.no_grad():
             y_ref = m(x)
         l0, l1 = m.layers
-        pk = dict(W0p=ops.pack_linear(l0.weight.detach().to(dev())), b0=l0.bias.detach().to(dev()),
-                  W1p=ops.pack_linear(l1.weight.detach().to(dev())), b1=l1.bias.detach().to(dev()),
+        pk = dict(W=ops.pack_stream([l0.weight.detach().to(dev()), l1.weight.detach().to(dev())]),
+                  bias=ops.bias_stream([l0.bias.detach().to(dev()), l1.bias.detach().to(dev())]),
                   din=din, dh=dh, dout=dout)
         y = ops.mlp2(x.to(dev()), pk)
         assert maxerr(y, y_ref) <= TOL, (din, dh, dout, rows)
