@@ -57,19 +57,20 @@ def set_noise_mode(mode: str, seed: Optional[int] = None, offset: int = 0, count
         _NoiseState.offset = int(offset)
 
 
-def _draw_uniform(shape: Tuple[int, int, int], device: torch.device) -> Tensor:
+def _draw_uniform(shape: Tuple[int, int, int], device: torch.device):
+    """The uniforms of one MLP_dict_softmax call: a tensor drawn as the reference does (host mode), or
+    a handle on the next shape-sized span of the device Philox stream, expanded inside the edge kernel."""
     if _NoiseState.mode == "host":
         return torch.rand(shape).float().to(device, non_blocking=True)
-    n = shape[0] * shape[1] * shape[2]
-    u = ops.philox_uniform(shape, _NoiseState.seed, _NoiseState.offset, device, _NoiseState.counter)
-    _NoiseState.offset += n
+    u = ops.PhiloxNoise(_NoiseState.seed, _NoiseState.offset, _NoiseState.counter)
+    _NoiseState.offset += shape[0] * shape[1] * shape[2]
     return u
 
 
 def _noise_iter(noise_u: Union[None, Tensor, Sequence[Tensor]]) -> Optional[Iterator[Tensor]]:
     if noise_u is None:
         return None
-    if isinstance(noise_u, torch.Tensor):
+    if isinstance(noise_u, (torch.Tensor, ops.PhiloxNoise)):
         return iter([noise_u])
     return iter(list(noise_u))
 

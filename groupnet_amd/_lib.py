@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgroupnet_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -36,7 +36,7 @@ SIGNATURES = {
     "gn_pack_linear_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "gn_node_mlp_f32": (_I, [_P] * 5 + [_I, _P]),
     "gn_node2edge_f32": (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _I, _P]),
-    "gn_edge_mlp_gumbel_f32": (_I, [_P] * 6 + [_I, _I, _F, _P]),
+    "gn_edge_mlp_gumbel_f32": (_I, [_P] * 6 + [_I, _I, _F, _U64, _U64, _P, _P]),
     "gn_agg_gather_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "gn_agg_mlp_f32": (_I, [_P] * 6 + [_I, _I, _P]),
     "gn_agg_scatter_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),

@@ -55,3 +55,37 @@ static inline void gn_allow_big_lds(K kernel) {
     done = true;
   }
 }
+
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): counter = (blk, 0),
+// key = seed.  Element i of the uniform stream is word (i & 3) of block (i >> 2), mapped to [0,1) by
+// (x >> 8) * 2^-24.
+__device__ __forceinline__ void gn_philox_block(unsigned long long blk, unsigned long long seed, uint32_t (&c)[4]) {
+  c[0] = (uint32_t)blk;
+  c[1] = (uint32_t)(blk >> 32);
+  c[2] = 0u;
+  c[3] = 0u;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0;
+    c[1] = n1;
+    c[2] = n2;
+    c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ float gn_philox_to_uniform(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
+__device__ __forceinline__ float gn_philox_uniform_at(unsigned long long idx, unsigned long long seed) {
+  uint32_t c[4];
+  gn_philox_block(idx >> 2, seed, c);
+  const int l = (int)(idx & 3);
+  const uint32_t x = l == 0 ? c[0] : (l == 1 ? c[1] : (l == 2 ? c[2] : c[3]));
+  return gn_philox_to_uniform(x);
+}

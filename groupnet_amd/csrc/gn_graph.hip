@@ -402,19 +402,6 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const float*
 // --------------------------------------------------------------------------------------------
 // Philox4x32-10 uniforms
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-  const uint32_t n1 = (uint32_t)p1;
-  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-  const uint32_t n3 = (uint32_t)p0;
-  c[0] = n0;
-  c[1] = n1;
-  c[2] = n2;
-  c[3] = n3;
-}
-
 __global__ __launch_bounds__(kBlock) void philox_uniform_kernel(float* __restrict__ U, unsigned long long n,
                                                                 unsigned long long seed, unsigned long long offset,
                                                                 const unsigned long long* __restrict__ offset_dev,
@@ -424,18 +411,12 @@ __global__ __launch_bounds__(kBlock) void philox_uniform_kernel(float* __restric
   for (unsigned long long t = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; t < nblk;
        t += (unsigned long long)gridDim.x * kBlock) {
     const unsigned long long blk = blk0 + t;
-    uint32_t c[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-      philox_round(c, k0, k1);
-      k0 += 0x9E3779B9u;
-      k1 += 0xBB67AE85u;
-    }
+    uint32_t c[4];
+    gn_philox_block(blk, seed, c);
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       const unsigned long long gidx = blk * 4 + l;
-      if (gidx >= offset && gidx - offset < n) U[gidx - offset] = (float)(c[l] >> 8) * 5.9604644775390625e-08f;
+      if (gidx >= offset && gidx - offset < n) U[gidx - offset] = gn_philox_to_uniform(c[l]);
     }
   }
 }
@@ -460,7 +441,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) 
 
 }  // namespace
 
-extern "C" int gn_abi_version(void) { return 2; }
+extern "C" int gn_abi_version(void) { return 3; }
 
 extern "C" const char* gn_strerror(int code) {
   switch (code) {

@@ -204,7 +204,9 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(const float* __res
                                                               const float* __restrict__ W,
                                                               const float* __restrict__ bias,
                                                               float* __restrict__ edge_feat, float* __restrict__ dist,
-                                                              int rows, int K, float tau) {
+                                                              int rows, int K, float tau, unsigned long long seed,
+                                                              unsigned long long offset,
+                                                              const unsigned long long* __restrict__ offset_dev) {
   const int blk = blockIdx.x * 4 + wave_id();
   if (blk * 32 >= rows) return;
   const RowBlock rb = row_block(rows, blk);
@@ -212,19 +214,31 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(const float* __res
   chain_begin(c, W, bias, rb.lane);
   f32x16 in[2], h1[4], z[2], h2[8], lg[1];
   load_rows<2>(edges, GN_FEAT, rb.row_ld, rb.h, in);
-  // the uniforms of this lane's features are fetched now, far ahead of the epilogue
-  const float* urow = U + (size_t)rb.row_ld * K;
+  // The uniforms of this lane's features: read from U (issued now, far ahead of the epilogue) or, with
+  // U == NULL, element row*K + f of the Philox stream at `offset` (+ the device counter) — computed on
+  // the VALU after the MFMAs are queued, so it costs no HBM traffic and no extra launch.
   float u[8];
+  if (U != nullptr) {
+    const float* urow = U + (size_t)rb.row_ld * K;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int f = feat_of(r, rb.h);
-    u[r] = f < K ? urow[f] : 0.5f;
+    for (int r = 0; r < 8; ++r) {
+      const int f = feat_of(r, rb.h);
+      u[r] = f < K ? urow[f] : 0.5f;
+    }
   }
   chain_linear<4, 2, true>(c, in, h1);
   chain_linear<2, 4, false>(c, h1, z);
   chain_linear<8, 2, true>(c, z, h2);
   chain_linear<1, 8, false>(c, h2, lg, true);
 
+  if (U == nullptr) {
+    const unsigned long long base = offset + (offset_dev ? *offset_dev : 0ull) + (unsigned long long)rb.row_ld * K;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int f = feat_of(r, rb.h);
+      u[r] = f < K ? gn_philox_uniform_at(base + f, seed) : 0.5f;
+    }
+  }
   // Epilogue.  Features 0..K-1 of `lg` are the logits of this lane's row, feature K the factor
   // pre-activation; a row's features are split over its two lanes (j, h=0) and (j, h=1).
   const float eps = 1e-10f;  // MS_HGNN_batch.py:446
@@ -444,14 +458,15 @@ extern "C" int gn_node_mlp_f32(const float* x, const float* W, const float* bias
 
 extern "C" int gn_edge_mlp_gumbel_f32(const float* edges, const float* U, const float* W, const float* bias,
                                       float* edge_feat, float* dist, int rows, int K, float tau,
-                                      gn_stream_t stream) {
-  const void* ptrs[] = {edges, U, W, bias, edge_feat, dist};
+                                      unsigned long long seed, unsigned long long offset,
+                                      const unsigned long long* offset_dev, gn_stream_t stream) {
+  const void* ptrs[] = {edges, W, bias, edge_feat, dist};
   for (const void* p : ptrs) GN_REQUIRE_PTR(p);
   const void* al[] = {edges, W, bias};
   for (const void* p : al) GN_REQUIRE_ALIGNED(p);
   if (rows <= 0 || K < 1 || K > 15 || !(tau > 0.f)) return GN_ERR_SHAPE;
   hipLaunchKernelGGL(edge_mlp_gumbel_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, edges, U, W,
-                     bias, edge_feat, dist, rows, K, tau);
+                     bias, edge_feat, dist, rows, K, tau, seed, offset, offset_dev);
   return gn_check_launch();
 }
 

@@ -166,16 +166,32 @@ def node2edge(xp: Tensor, pq: Tensor, H: Optional[Tensor], w2: Tensor, b2: float
 
 
 # ---- A4 ------------------------------------------------------------------------------------------
-def edge_mlp_gumbel(edges: Tensor, U: Tensor, pk: dict, K: int, tau: float = 0.5) -> Tuple[Tensor, Tensor]:
+class PhiloxNoise:
+    """Uniforms generated inside the edge kernel: element (row, k) of a (B,E,K) draw is element
+    offset (+ device counter) + row*K + k of the Philox4x32-10 stream `seed`."""
+    __slots__ = ("seed", "offset", "counter")
+
+    def __init__(self, seed: int, offset: int = 0, counter: Optional[Tensor] = None):
+        if counter is not None and not (counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1):
+            raise ValueError("counter: a 1-element int64 GPU tensor")
+        self.seed, self.offset, self.counter = int(seed) & (2**64 - 1), int(offset), counter
+
+
+def edge_mlp_gumbel(edges: Tensor, U, pk: dict, K: int, tau: float = 0.5) -> Tuple[Tensor, Tensor]:
+    """(edge_feat, dist) of MLP_dict_softmax.  `U`: a (B,E,K) tensor of uniforms, or a PhiloxNoise."""
     _req(edges, "edges", (None, None, FEAT))
     B, E, _ = edges.shape
-    _req(U, "noise_u", (B, E, K))
-    _same_device(edges, U)
+    if isinstance(U, PhiloxNoise):
+        u_ptr, seed, off, ctr = _P(0), U.seed, U.offset, _ptr(U.counter)
+    else:
+        _req(U, "noise_u", (B, E, K))
+        _same_device(edges, U)
+        u_ptr, seed, off, ctr = _ptr(U), 0, 0, _P(0)
     edge_feat = torch.empty((B, E, K), dtype=edges.dtype, device=edges.device)
     dist = torch.empty_like(edge_feat)
     with torch.cuda.device(edges.device):
-        check(load().gn_edge_mlp_gumbel_f32(_ptr(edges), _ptr(U), _ptr(pk["W"]), _ptr(pk["bias"]), _ptr(edge_feat),
-                                            _ptr(dist), B * E, K, float(tau), stream_handle()),
+        check(load().gn_edge_mlp_gumbel_f32(_ptr(edges), u_ptr, _ptr(pk["W"]), _ptr(pk["bias"]), _ptr(edge_feat),
+                                            _ptr(dist), B * E, K, float(tau), seed, off, ctr, stream_handle()),
               "gn_edge_mlp_gumbel_f32")
     return edge_feat, dist
 

@@ -107,9 +107,14 @@ int gn_node2edge_f32(const float* xp, const float* pq, const float* H, const flo
  *   Wd0 = [MLP_distribution.layers.0 ; MLP_factor.layers.0] and Wd1 is the block matrix whose rows
  *   0..K-1 are [MLP_distribution.layers.1, 0] and row K is [0, MLP_factor.layers.1];
  * bias = [128 | 64 | 256 | 32] in the same order (bd1: K logits biases, then the factor bias, zeros).
- * edges (rows,64), U (rows,K) uniforms in [0,1) -> edge_feat (rows,K), dist (rows,K).  K <= 15. */
+ * edges (rows,64), U (rows,K) uniforms in [0,1) -> edge_feat (rows,K), dist (rows,K).  K <= 15.
+ * U == NULL: the uniforms are generated inside the kernel — element row*K + k is element
+ * offset (+ *offset_dev if not NULL) + row*K + k of the Philox stream `seed`, exactly what
+ * gn_philox_uniform_f32 would have written into U. */
 int gn_edge_mlp_gumbel_f32(const float* edges, const float* U, const float* W, const float* bias,
-                           float* edge_feat, float* dist, int rows, int K, float tau, gn_stream_t stream);
+                           float* edge_feat, float* dist, int rows, int K, float tau,
+                           unsigned long long seed, unsigned long long offset,
+                           const unsigned long long* offset_dev, gn_stream_t stream);
 
 /* ---- A5: hyperedge aggregation --------------------------------------------------------------
  * gather: eo = H ori            (edge_aggregation.forward, MS_HGNN_batch.py:263)

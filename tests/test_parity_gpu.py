@@ -416,3 +416,21 @@ def test_graphed_multiscale_fresh_reproducible_noise():
         G.set_noise_mode("host")
     assert torch.equal(o1, e1) and torch.equal(o2, e2)
     assert int(g.counter.item()) == 2 * g.draws_per_step
+
+
+def test_in_kernel_philox_equals_uniform_tensor():
+    """U == NULL path of the edge kernel draws exactly the stream gn_philox_uniform_f32 writes."""
+    from groupnet_amd import ops
+    torch.manual_seed(8)
+    pair, hyper = build_modules(1)
+    hyper.to(dev())
+    B, E, K = 37, 11, 10
+    edges = torch.randn(B, E, 64, device=dev())
+    pk = hyper.nmp_mlp_start._packed()
+    ctr = torch.tensor([1000], dtype=torch.int64, device=dev())
+    U = ops.philox_uniform((B, E, K), 77, 123 + 1000, dev())
+    ef_a, d_a = ops.edge_mlp_gumbel(edges, U, pk, K)
+    ef_b, d_b = ops.edge_mlp_gumbel(edges, ops.PhiloxNoise(77, 123, ctr), pk, K)
+    assert torch.equal(ef_a, ef_b) and torch.equal(d_a, d_b)
+    ef_c, _ = ops.edge_mlp_gumbel(edges, ops.PhiloxNoise(77, 124, ctr), pk, K)
+    assert not torch.equal(ef_a, ef_c)
