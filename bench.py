@@ -13,7 +13,7 @@ each rank owns 512 scenes (BASELINE config 3: 4096 scenes over 8 GPUs — weak s
 ends with ONE all-gather of the output embeddings over RCCL/xGMI.  The step is a captured hipGraph.
 
 Rank 0 prints one JSON line.  Besides the contract fields it carries
-  roofline      the dominant kernel (typed aggregation MLP of the pairwise module, fp32 MFMA):
+  roofline      the dominant kernel (typed aggregation MLP, all modules in one grouped launch, fp32 MFMA):
                 algorithmic FLOPs per launch / its average duration, measured here with HIP events on
                 the stream it is launched on, in an instrumented pass over the same K steps;
   agg_hbm       the hyperedge aggregation gather+scatter kernels against the HBM roofline at
@@ -54,19 +54,19 @@ def agg_hbm_bytes(B, N, E):
 
 
 class Probe:
-    """Brackets every launch of one kernel (name, K) with HIP events on its own stream."""
+    """Brackets every launch of one named kernel with HIP events on the stream it is launched on."""
 
-    def __init__(self, name, K):
-        self.name, self.K = name, K
+    def __init__(self, name):
+        self.name = name
         self.pairs, self._open = [], None
 
-    def __call__(self, name, K, rows, before):
-        if name != self.name or K != self.K:
+    def __call__(self, name, flops, before):
+        if name != self.name:
             return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
         if before:
-            self._open = (ev, rows)
+            self._open = (ev, flops)
         else:
             self.pairs.append((self._open[0], ev, self._open[1]))
 
@@ -196,7 +196,7 @@ def main():
         roof = agg = None
         if rank == 0:
             G.set_noise_mode("device", seed=99)
-            probe = Probe("agg_mlp", block.interaction.edge_types)
+            probe = Probe("agg_mlp")
             ops.launch_probe = probe
             torch.cuda.synchronize()
             for _ in range(min(args.steps, 50)):
@@ -205,14 +205,12 @@ def main():
             ops.launch_probe = None
             torch.cuda.synchronize()
             ms = probe.mean_ms()
-            rows = probe.pairs[0][2]
-            fl = agg_mlp_flops(rows, block.interaction.edge_types)
+            fl = probe.pairs[0][2]
             ach = fl / (ms * 1e-3) / 1e12
-            roof = dict(kernel="agg_mlp_kernel<6> (typed aggregation MLP, pairwise module)", bound="mfma",
-                        achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+            roof = dict(kernel="agg_mlp_kernel (typed aggregation MLP, one grouped launch: pairwise + 3 hyper modules)",
+                        bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
-                        avg_launch_us=round(ms * 1e3, 2), flops_per_launch=fl, rows_per_launch=rows,
-                        launches_timed=len(probe.pairs))
+                        avg_launch_us=round(ms * 1e3, 2), flops_per_launch=fl, launches_timed=len(probe.pairs))
             # ---- north_star: hyperedge aggregation gather+scatter vs HBM at N=11 / B=4096 ----------------
             Bb = 4096
             ori = torch.randn(Bb, N, 64, device=dev)

@@ -292,7 +292,7 @@ class _MessagePassing(nn.Module):
             hit = self._pk_mlp[id(mlp)]
         return hit[1]
 
-    # -- stages ----------------------------------------------------------------------------------
+    # -- stages (single-module faces of the grouped engine below) -----------------------------------
     def _node2edge(self, x: Tensor, H: Optional[Tensor], idx: int) -> Tensor:
         pk = self._packed_n2e(idx)
         xp, pq = ops.node_mlp(x, pk)
@@ -303,29 +303,73 @@ class _MessagePassing(nn.Module):
 
     def _run(self, h: Tensor, H: Optional[Tensor], E: int, noise_u, out: Optional[Tensor] = None
              ) -> Tuple[Tensor, Tensor]:
-        B = h.shape[0]
-        K = self.edge_types
-        given = _noise_iter(noise_u)
+        return run_message_passing([self], [h], [H], [noise_u], [out])[0]
 
-        def next_u() -> Tensor:
-            if given is not None:
-                try:
-                    return next(given)
-                except StopIteration:
-                    raise ValueError(f"noise_u: {self.nmp_layers} uniform tensors of shape ({B},{E},{K}) needed")
-            return _draw_uniform((B, E, K), h.device)
 
-        edge_feat, factors = self.nmp_mlp_start(self._node2edge(h, H, 0), noise_u=next_u())
-        node_feat, idx = h, 0
-        for l, stage in enumerate(self.nmp_mlps):
-            if l % 2 == 0:
-                node_feat = ops.mlp2(self._edge2node(edge_feat, node_feat, H, idx), self._packed_mlp2(stage))
-                idx += 1
-            else:
-                edge_feat, _ = stage(self._node2edge(node_feat, H, idx), noise_u=next_u())
-        node_feat = ops.mlp2(self._edge2node(edge_feat, node_feat, H, idx), self._packed_mlp2(self.nmp_mlp_end),
-                             out=out)
-        return node_feat, factors
+def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor], Hs: Sequence[Optional[Tensor]],
+                        noises: Sequence, outs: Sequence[Optional[Tensor]]) -> List[Tuple[Tensor, Tensor]]:
+    """The message-passing rounds of SEVERAL modules over the same scenes, stage by stage, each stage
+    ONE grouped launch (model/MS_HGNN_batch.py:174-195 and :425-441 for every module at once).
+
+    mods[i] runs on hs[i] (B,N,64) with incidence Hs[i] (None = the implicit pairwise graph);
+    noises[i] is None (draw), a tensor / PhiloxNoise, or a list of nmp_layers of them; outs[i]
+    optionally receives node_feat.  Returns [(node_feat, factors)] per module.  All modules must
+    share nmp_layers and bottleneck_dim (they do in every caller of the reference)."""
+    n = len(mods)
+    if not (n == len(hs) == len(Hs) == len(noises) == len(outs)) or n == 0:
+        raise ValueError("run_message_passing: one h, H, noise and out per module")
+    nmp = mods[0].nmp_layers
+    if any(m.nmp_layers != nmp or m.bottleneck_dim != mods[0].bottleneck_dim for m in mods):
+        raise ValueError("grouped modules must share nmp_layers and bottleneck_dim")
+    B, N = hs[0].shape[0], hs[0].shape[1]
+    Es = [N * N if H is None else H.shape[1] for H in Hs]
+    given = [_noise_iter(u) for u in noises]
+
+    def next_u(i: int):
+        if given[i] is not None:
+            try:
+                return next(given[i])
+            except StopIteration:
+                raise ValueError(f"noise_u: {nmp} uniform tensors of shape ({B},{Es[i]},{mods[i].edge_types}) needed")
+        return _draw_uniform((B, Es[i], mods[i].edge_types), hs[i].device)
+
+    def node2edge(xs: Sequence[Tensor], idx: int) -> List[Tensor]:
+        pks = [m._packed_n2e(idx) for m in mods]
+        xpq = ops.node_mlp_grouped([(x, pk) for x, pk in zip(xs, pks)])
+        return ops.node2edge_grouped([(xp, pq, H, pk["w2"], pk["b2"]) for (xp, pq), H, pk in zip(xpq, Hs, pks)])
+
+    def edge_mlp(stages, edges: Sequence[Tensor]):
+        # draws happen module by module, in the order given — the reference's RNG order per call site
+        us = [next_u(i) for i in range(n)]
+        return ops.edge_mlp_gumbel_grouped([(e, u, st._packed(), st.bottleneck_dim)
+                                            for e, u, st in zip(edges, us, stages)], _GUMBEL_TAU)
+
+    def edge2node(edge_feats: Sequence[Tensor], oris: Sequence[Tensor], idx: int) -> List[Tensor]:
+        aggs = [m.edge_aggregation_list[idx] for m in mods]
+        eos = ops.agg_gather_grouped(list(zip(oris, Hs)))
+        feats = ops.agg_mlp_grouped([(eo, ef, a._packed(), a.edge_types) for eo, ef, a in zip(eos, edge_feats, aggs)])
+        return ops.agg_scatter_grouped([(f, H, o) for f, H, o in zip(feats, Hs, oris)])
+
+    res = edge_mlp([m.nmp_mlp_start for m in mods], node2edge(hs, 0))
+    edge_feats, factors = [r[0] for r in res], [r[1] for r in res]
+    node_feats, idx = list(hs), 0
+    for l in range(2 * (nmp - 1)):
+        stages = [m.nmp_mlps[l] for m in mods]
+        if l % 2 == 0:
+            agg = edge2node(edge_feats, node_feats, idx)
+            node_feats = ops.mlp2_grouped([(a, m._packed_mlp2(st), None) for a, m, st in zip(agg, mods, stages)])
+            idx += 1
+        else:
+            edge_feats = [r[0] for r in edge_mlp(stages, node2edge(node_feats, idx))]
+    agg = edge2node(edge_feats, node_feats, idx)
+    ends = [(a, m._packed_mlp2(m.nmp_mlp_end), o) for a, m, o in zip(agg, mods, outs)]
+    # the last MLP writes in place when `out` is given; grouped when every group has the same stride
+    strides = {(-1 if o is None else o.stride(-2)) for o in outs}
+    if len(strides) == 1:
+        node_feats = ops.mlp2_grouped(ends)
+    else:
+        node_feats = [ops.mlp2(*e) for e in ends]
+    return list(zip(node_feats, factors))
 
 
 class MS_HGNN_oridinary(_MessagePassing):

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgroupnet_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -25,6 +25,38 @@ _F = ctypes.c_float
 _SZ = ctypes.c_size_t
 _U64 = ctypes.c_ulonglong
 
+class NodeGroup(ctypes.Structure):      # gn_node_group_t
+    _fields_ = [("x", _P), ("W", _P), ("bias", _P), ("xp", _P), ("pq", _P)]
+
+
+class N2EGroup(ctypes.Structure):       # gn_n2e_group_t
+    _fields_ = [("xp", _P), ("pq", _P), ("H", _P), ("w2", _P), ("edges", _P), ("b2", _F), ("E", _I)]
+
+
+class EdgeGroup(ctypes.Structure):      # gn_edge_group_t
+    _fields_ = [("edges", _P), ("U", _P), ("W", _P), ("bias", _P), ("edge_feat", _P), ("dist", _P),
+                ("philox_offset", _U64), ("rows", _I), ("K", _I)]
+
+
+class GatherGroup(ctypes.Structure):    # gn_gather_group_t
+    _fields_ = [("ori", _P), ("H", _P), ("eo", _P), ("E", _I)]
+
+
+class AggGroup(ctypes.Structure):       # gn_agg_group_t
+    _fields_ = [("eo", _P), ("edge_feat", _P), ("W", _P), ("b1", _P), ("b2", _P), ("feat", _P), ("rows", _I),
+                ("K", _I)]
+
+
+class ScatterGroup(ctypes.Structure):   # gn_scatter_group_t
+    _fields_ = [("feat", _P), ("H", _P), ("ori", _P), ("out", _P), ("E", _I)]
+
+
+class Mlp2Group(ctypes.Structure):      # gn_mlp2_group_t
+    _fields_ = [("x", _P), ("W", _P), ("bias", _P), ("y", _P)]
+
+
+MAX_GROUPS = 10
+
 # name -> (restype, argtypes); mirrors include/groupnet_hip.h one to one
 SIGNATURES = {
     "gn_abi_version": (_I, []),
@@ -34,13 +66,13 @@ SIGNATURES = {
     "gn_affinity_topk_f32": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_I), _I, _I, _I, _I, _P]),
     "gn_packed_elems": (_SZ, [_I, _I]),
     "gn_pack_linear_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "gn_node_mlp_f32": (_I, [_P] * 5 + [_I, _P]),
-    "gn_node2edge_f32": (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _I, _P]),
-    "gn_edge_mlp_gumbel_f32": (_I, [_P] * 6 + [_I, _I, _F, _U64, _U64, _P, _P]),
-    "gn_agg_gather_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "gn_agg_mlp_f32": (_I, [_P] * 6 + [_I, _I, _P]),
-    "gn_agg_scatter_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
-    "gn_mlp2_f32": (_I, [_P] * 4 + [_I, _I, _I, _I, _I, _P]),
+    "gn_node_mlp_f32": (_I, [ctypes.POINTER(NodeGroup), _I, _I, _P]),
+    "gn_node2edge_f32": (_I, [ctypes.POINTER(N2EGroup), _I, _I, _I, _P]),
+    "gn_edge_mlp_gumbel_f32": (_I, [ctypes.POINTER(EdgeGroup), _I, _F, _U64, _P, _P]),
+    "gn_agg_gather_f32": (_I, [ctypes.POINTER(GatherGroup), _I, _I, _I, _P]),
+    "gn_agg_mlp_f32": (_I, [ctypes.POINTER(AggGroup), _I, _P]),
+    "gn_agg_scatter_f32": (_I, [ctypes.POINTER(ScatterGroup), _I, _I, _I, _F, _P]),
+    "gn_mlp2_f32": (_I, [ctypes.POINTER(Mlp2Group), _I, _I, _I, _I, _I, _I, _P]),
     "gn_philox_uniform_f32": (_I, [_P, _SZ, _U64, _U64, _P, _P]),
     "gn_counter_add_u64": (_I, [_P, _U64, _P]),
 }

@@ -159,22 +159,39 @@ __global__ __launch_bounds__(kBlock) void topk_incidence_kernel(const float* __r
 }
 
 // --------------------------------------------------------------------------------------------
-// A3 second half: attention-weighted node -> edge pooling.  One wave per hyperedge.
+// group tables (kernel arguments, by value): one launch serves the same stage of several modules
 // --------------------------------------------------------------------------------------------
-// Members of the edge (nodes with H != 0) are compacted into LDS; non-members enter the
-// softmax only as exp(0 - max) terms, exactly as softmax(att * H) treats them
-// (MS_HGNN_batch.py:135-137,366-368).
-template <bool PAIRWISE>
-__global__ __launch_bounds__(kBlock) void node2edge_kernel(const float* __restrict__ xp, const float* __restrict__ pq,
-                                                           const float* __restrict__ H, const float* __restrict__ w2,
-                                                           float b2, float* __restrict__ edges, int N, int E,
-                                                           long long total_edges) {
+template <typename G>
+struct GroupTable {
+  G g[GN_MAX_GROUPS];
+  long long first[GN_MAX_GROUPS + 1];  // prefix of work items (meaning depends on the kernel)
+  int n;
+};
+template <typename G>
+__device__ __forceinline__ int find_group(const GroupTable<G>& t, long long item) {
+  int g = 0;
+  while (g + 1 < t.n && item >= t.first[g + 1]) ++g;
+  return g;
+}
+
+// --------------------------------------------------------------------------------------------
+// A3 second half: attention-weighted node -> edge pooling
+// --------------------------------------------------------------------------------------------
+// Hyper modules: one wave per hyperedge.  Members of the edge (nodes with H != 0) are compacted
+// into LDS; non-members enter the softmax only as exp(0 - max) terms, exactly as
+// softmax(att * H) treats them (MS_HGNN_batch.py:135-137,366-368).  `first` counts edges (waves).
+__global__ __launch_bounds__(kBlock) void node2edge_kernel(GroupTable<gn_n2e_group_t> T, int N) {
   extern __shared__ __align__(16) float lds[];
   const int wave = gn_uniform((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-  const long long eg_raw = (long long)blockIdx.x * (kBlock / 64) + wave;
-  const bool live = eg_raw < total_edges;  // dead waves redo the last edge and skip the store
-  const long long eg = live ? eg_raw : total_edges - 1;
+  const long long total = T.first[T.n];
+  const long long w_raw = (long long)blockIdx.x * (kBlock / 64) + wave;
+  const bool live = w_raw < total;  // dead waves redo the last edge and skip the store
+  const long long w = live ? w_raw : total - 1;
+  const int gi = gn_uniform(find_group(T, w));
+  const gn_n2e_group_t G = T.g[gi];
+  const int E = G.E;
+  const long long eg = w - T.first[gi];
   const int b = (int)(eg / E), e = (int)(eg - (long long)b * E);
   // per-wave LDS: idx[N] (int), hval[N], att[N]
   float* base = lds + (size_t)wave * 3 * N;
@@ -183,43 +200,27 @@ __global__ __launch_bounds__(kBlock) void node2edge_kernel(const float* __restri
   float* s_att = base + 2 * N;
 
   int cnt = 0;
-  if (PAIRWISE) {
-    const int i = e / N, j = e - i * N;
-    if (lane == 0) {
-      if (i == j) {
-        s_idx[0] = i;
-        s_h[0] = 2.f;
-      } else {  // ascending node order, as a dense H row would be scanned
-        s_idx[0] = min(i, j);
-        s_h[0] = 1.f;
-        s_idx[1] = max(i, j);
-        s_h[1] = 1.f;
-      }
+  const float* Hrow = G.H + ((size_t)b * E + e) * N;
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const int n = n0 + lane;
+    const float hv = n < N ? Hrow[n] : 0.f;
+    const unsigned long long mask = __ballot(hv != 0.f);
+    if (hv != 0.f) {
+      const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      s_idx[pos] = n;
+      s_h[pos] = hv;
     }
-    cnt = (i == j) ? 1 : 2;
-  } else {
-    const float* Hrow = H + ((size_t)b * E + e) * N;
-    for (int n0 = 0; n0 < N; n0 += 64) {
-      const int n = n0 + lane;
-      const float hv = n < N ? Hrow[n] : 0.f;
-      const unsigned long long mask = __ballot(hv != 0.f);
-      if (hv != 0.f) {
-        const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-        s_idx[pos] = n;
-        s_h[pos] = hv;
-      }
-      cnt += __popcll(mask);
-    }
+    cnt += __popcll(mask);
   }
   __syncthreads();
 
-  const float* pqb = pq + (size_t)b * N * GN_FEAT;
-  const float* xpb = xp + (size_t)b * N * GN_FEAT;
+  const float* pqb = G.pq + (size_t)b * N * GN_FEAT;
+  const float* xpb = G.xp + (size_t)b * N * GN_FEAT;
   // Q_e = sum_n H[e,n] * Qn_n      (lanes 32..63 hold channel c of Qn)
   float qe = 0.f;
   for (int m = 0; m < cnt; ++m) qe = fmaf(s_h[m], pqb[(size_t)s_idx[m] * GN_FEAT + lane], qe);
   const float qlo = __shfl(qe, 32 + c, GN_WAVE);  // both halves now see Q_e[c]
-  const float w2c = w2[c];
+  const float w2c = G.w2[c];
   // att for two members per step: half h takes member 2*t + h
   for (int m0 = 0; m0 < cnt; m0 += 2) {
     const int m = m0 + h;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_kernel(const float* __restri
     const float p = pqb[(size_t)n * GN_FEAT + c];
     float t = valid ? w2c * fmaxf(p + qlo, 0.f) : 0.f;
     t = gn_half_sum(t);
-    if (valid && c == 0) s_att[m] = t + b2;
+    if (valid && c == 0) s_att[m] = t + G.b2;
   }
   __syncthreads();
   // softmax over all N nodes of v_n = att_n * H[e,n]  (0 for non-members)
@@ -246,30 +247,121 @@ __global__ __launch_bounds__(kBlock) void node2edge_kernel(const float* __restri
     const float wgt = expf(s_att[m] * hv - mx) / sum * hv;
     acc = fmaf(wgt, xpb[(size_t)s_idx[m] * GN_FEAT + lane], acc);
   }
-  if (live) edges[(size_t)eg * GN_FEAT + lane] = acc;
+  if (live) G.edges[(size_t)eg * GN_FEAT + lane] = acc;
+}
+
+// Pairwise module (MS_HGNN_oridinary): edge e = i*N + j touches i and j with weight 1 (2 on the
+// diagonal), so only att[e,i] and att[e,j] matter and Q_e = Qn_i + Qn_j.  A workgroup stages the
+// x' and pq rows of SG scenes in LDS (pq rows padded to 65 floats: lanes read different rows at the
+// same channel), then walks bands of 256 edges: phase A one thread per edge evaluates the two
+// attention logits and the softmax weights, phase B the band's 256 x 16 float4 outputs are written
+// as consecutive 16-byte pieces.
+__global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group_t G, int B, int N, int SG,
+                                                                   int bands) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int LDP = GN_FEAT + 1;
+  const int E = N * N;
+  const int b0 = (blockIdx.x / bands) * SG;
+  const int band = blockIdx.x % bands;
+  const int sg = min(SG, B - b0);
+  float* s_xp = lds;                                // sg x N x 64
+  float* s_pq = s_xp + (size_t)SG * N * GN_FEAT;    // sg x N x 65
+  float* s_w = s_pq + (size_t)SG * N * LDP;         // 256 x 2 edge weights of the current band
+  float* s_w2 = s_w + 2 * kBlock;                   // 32
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(G.xp + (size_t)b0 * N * GN_FEAT);
+    f32x4* dst = reinterpret_cast<f32x4*>(s_xp);
+    for (int idx = threadIdx.x; idx < sg * N * 16; idx += kBlock) dst[idx] = src[idx];
+    const float* psrc = G.pq + (size_t)b0 * N * GN_FEAT;
+    for (int idx = threadIdx.x; idx < sg * N * GN_FEAT; idx += kBlock) {
+      const int r = idx >> 6, cc = idx & 63;
+      s_pq[r * LDP + cc] = psrc[idx];
+    }
+    if (threadIdx.x < 32) s_w2[threadIdx.x] = G.w2[threadIdx.x];
+  }
+  __syncthreads();
+  const long long total = (long long)sg * E;  // edges of this workgroup's scenes
+  const long long per_band = ((total + bands - 1) / bands + kBlock - 1) / kBlock * kBlock;
+  const long long lo = band * per_band, hi = min(total, lo + per_band);
+  for (long long base = lo; base < hi; base += kBlock) {
+    const long long eidx = base + threadIdx.x;
+    if (eidx < hi) {
+      const int s = (int)(eidx / E), e = (int)(eidx - (long long)s * E);
+      const int i = e / N, j = e - i * N;
+      const float* pi = s_pq + (size_t)(s * N + i) * LDP;
+      const float* pj = s_pq + (size_t)(s * N + j) * LDP;
+      float ai = 0.f, aj = 0.f;
+      if (i == j) {
+#pragma unroll 8
+        for (int cch = 0; cch < 32; ++cch) ai = fmaf(s_w2[cch], fmaxf(pi[cch] + 2.f * pi[32 + cch], 0.f), ai);
+        ai += G.b2;
+        // H = 2 on the self-loop: v = 2*att, the other N-1 nodes contribute exp(0)
+        const float v = 2.f * ai;
+        const float mx = N > 1 ? fmaxf(v, 0.f) : v;
+        const float ev = expf(v - mx);
+        const float sum = ev + (float)(N - 1) * expf(0.f - mx);
+        s_w[2 * threadIdx.x] = ev / sum * 2.f;
+        s_w[2 * threadIdx.x + 1] = 0.f;
+      } else {
+#pragma unroll 8
+        for (int cch = 0; cch < 32; ++cch) {
+          const float q = pi[32 + cch] + pj[32 + cch];
+          ai = fmaf(s_w2[cch], fmaxf(pi[cch] + q, 0.f), ai);
+          aj = fmaf(s_w2[cch], fmaxf(pj[cch] + q, 0.f), aj);
+        }
+        ai += G.b2;
+        aj += G.b2;
+        const float mx = N > 2 ? fmaxf(fmaxf(ai, aj), 0.f) : fmaxf(ai, aj);
+        const float ei = expf(ai - mx), ej = expf(aj - mx);
+        const float sum = (ei + ej) + (float)(N - 2) * expf(0.f - mx);
+        s_w[2 * threadIdx.x] = ei / sum;
+        s_w[2 * threadIdx.x + 1] = ej / sum;
+      }
+    }
+    __syncthreads();
+    const int nb = (int)min((long long)kBlock, hi - base);
+    f32x4* dst = reinterpret_cast<f32x4*>(G.edges + ((size_t)b0 * E + base) * GN_FEAT);
+    for (int idx = threadIdx.x; idx < nb * 16; idx += kBlock) {
+      const int t = idx >> 4, d = idx & 15;
+      const long long eidx = base + t;
+      const int s = (int)(eidx / E), e = (int)(eidx - (long long)s * E);
+      const int i = e / N, j = e - i * N;
+      const float wi = s_w[2 * t], wj = s_w[2 * t + 1];
+      const f32x4 xi = reinterpret_cast<const f32x4*>(s_xp + (size_t)(s * N + i) * GN_FEAT)[d];
+      const f32x4 xj = reinterpret_cast<const f32x4*>(s_xp + (size_t)(s * N + j) * GN_FEAT)[d];
+      f32x4 r = {fmaf(wj, xj[0], wi * xi[0]), fmaf(wj, xj[1], wi * xi[1]), fmaf(wj, xj[2], wi * xi[2]),
+                 fmaf(wj, xj[3], wi * xi[3])};
+      dst[idx] = r;
+    }
+    __syncthreads();
+  }
 }
 
 // --------------------------------------------------------------------------------------------
 // A5: hyperedge aggregation — gather (eo = H ori) and scatter (out = cat(H^T feat, ori) / N)
 // --------------------------------------------------------------------------------------------
-// A workgroup owns G consecutive scenes x an edge band [e0, e0+TE).  The scenes' ori tiles and
-// the H band are contiguous in HBM, so they stream into LDS as whole 16-byte pieces; each
-// thread then produces float4 outputs that are again contiguous across the workgroup.
-__global__ __launch_bounds__(kBlock) void agg_gather_kernel(const float* __restrict__ ori, const float* __restrict__ H,
-                                                            float* __restrict__ eo, int B, int N, int E, int G,
-                                                            int TE) {
+// A workgroup owns G consecutive scenes x an edge band [e0, e0+TE) of the group blockIdx.z.  The
+// scenes' ori tiles and the H band are contiguous in HBM, so they stream into LDS as whole 16-byte
+// pieces; each thread then produces float4 outputs that are again contiguous across the workgroup.
+struct GatherTable {
+  gn_gather_group_t g[GN_MAX_GROUPS];
+};
+__global__ __launch_bounds__(kBlock) void agg_gather_kernel(GatherTable T, int B, int N, int G, int TE) {
   extern __shared__ __align__(16) float lds[];
+  const gn_gather_group_t Gr = T.g[blockIdx.z];
+  const int E = Gr.E;
   const int b0 = blockIdx.x * G, e0 = blockIdx.y * TE;
+  if (e0 >= E) return;  // groups with fewer edges (E = 1 when scale == N) need fewer bands
   const int g = min(G, B - b0), te = min(TE, E - e0);
   float* s_ori = lds;                           // g x N x 64
   float* s_H = lds + (size_t)G * N * GN_FEAT;   // g x te x N
   {
-    const f32x4* src = reinterpret_cast<const f32x4*>(ori + (size_t)b0 * N * GN_FEAT);
+    const f32x4* src = reinterpret_cast<const f32x4*>(Gr.ori + (size_t)b0 * N * GN_FEAT);
     f32x4* dst = reinterpret_cast<f32x4*>(s_ori);
     for (int idx = threadIdx.x; idx < g * N * (GN_FEAT / 4); idx += kBlock) dst[idx] = src[idx];
     for (int idx = threadIdx.x; idx < g * te * N; idx += kBlock) {
       const int s = idx / (te * N), r = idx - s * te * N;
-      s_H[idx] = H[((size_t)(b0 + s) * E + e0) * N + r];
+      s_H[idx] = Gr.H[((size_t)(b0 + s) * E + e0) * N + r];
     }
   }
   __syncthreads();
@@ -287,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void agg_gather_kernel(const float* __restr
       acc[2] = fmaf(hv, v[2], acc[2]);
       acc[3] = fmaf(hv, v[3], acc[3]);
     }
-    reinterpret_cast<f32x4*>(eo + ((size_t)(b0 + s) * E + e0 + e) * GN_FEAT)[d] = acc;
+    reinterpret_cast<f32x4*>(Gr.eo + ((size_t)(b0 + s) * E + e0 + e) * GN_FEAT)[d] = acc;
   }
 }
 
@@ -309,20 +401,24 @@ __global__ __launch_bounds__(kBlock) void agg_gather_pairwise_kernel(const float
   }
 }
 
-__global__ __launch_bounds__(kBlock) void agg_scatter_kernel(const float* __restrict__ feat,
-                                                             const float* __restrict__ H,
-                                                             const float* __restrict__ ori, float* __restrict__ out,
-                                                             int B, int N, int E, int G, float fN) {
+struct ScatterTable {
+  gn_scatter_group_t g[GN_MAX_GROUPS];
+};
+// blockIdx.y = group; LDS sized for the largest E of the launch
+__global__ __launch_bounds__(kBlock) void agg_scatter_kernel(ScatterTable T, int B, int N, int G, int Emax,
+                                                             float fN) {
   extern __shared__ __align__(16) float lds[];
+  const gn_scatter_group_t Gr = T.g[blockIdx.y];
+  const int E = Gr.E;
   const int b0 = blockIdx.x * G;
   const int g = min(G, B - b0);
-  float* s_feat = lds;                            // g x E x 64
-  float* s_H = lds + (size_t)G * E * GN_FEAT;     // g x E x N
+  float* s_feat = lds;                              // g x E x 64
+  float* s_H = lds + (size_t)G * Emax * GN_FEAT;    // g x E x N
   {
-    const f32x4* src = reinterpret_cast<const f32x4*>(feat + (size_t)b0 * E * GN_FEAT);
+    const f32x4* src = reinterpret_cast<const f32x4*>(Gr.feat + (size_t)b0 * E * GN_FEAT);
     f32x4* dst = reinterpret_cast<f32x4*>(s_feat);
     for (int idx = threadIdx.x; idx < g * E * (GN_FEAT / 4); idx += kBlock) dst[idx] = src[idx];
-    const float* hs = H + (size_t)b0 * E * N;
+    const float* hs = Gr.H + (size_t)b0 * E * N;
     for (int idx = threadIdx.x; idx < g * E * N; idx += kBlock) s_H[idx] = hs[idx];
   }
   __syncthreads();
@@ -343,10 +439,10 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_kernel(const float* __rest
         acc[3] = fmaf(hv, v[3], acc[3]);
       }
     } else {
-      acc = reinterpret_cast<const f32x4*>(ori + ((size_t)(b0 + s) * N + n) * GN_FEAT)[d - 16];
+      acc = reinterpret_cast<const f32x4*>(Gr.ori + ((size_t)(b0 + s) * N + n) * GN_FEAT)[d - 16];
     }
     f32x4 r = {acc[0] / fN, acc[1] / fN, acc[2] / fN, acc[3] / fN};
-    reinterpret_cast<f32x4*>(out + ((size_t)(b0 + s) * N + n) * 2 * GN_FEAT)[d] = r;
+    reinterpret_cast<f32x4*>(Gr.out + ((size_t)(b0 + s) * N + n) * 2 * GN_FEAT)[d] = r;
   }
 }
 
@@ -368,8 +464,7 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const float*
       acc = {0.f, 0.f, 0.f, 0.f};
       const f32x4* f4 = reinterpret_cast<const f32x4*>(feat + (size_t)b * E * GN_FEAT) + d;
       if (PAIRWISE) {
-        // edges in ascending e: (i,n) for i<n and (n,j) interleave, but fp32 tolerance makes the
-        // order immaterial; (n,n) counts twice (H = 2 on self-loops)
+        // (n,n) counts twice (H = 2 on self-loops); fp32 tolerance makes the edge order immaterial
         for (int j = 0; j < N; ++j) {
           const f32x4 v = f4[(size_t)(n * N + j) * 16];
           const f32x4 w = f4[(size_t)(j * N + n) * 16];
@@ -441,7 +536,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) 
 
 }  // namespace
 
-extern "C" int gn_abi_version(void) { return 3; }
+extern "C" int gn_abi_version(void) { return 4; }
 
 extern "C" const char* gn_strerror(int code) {
   switch (code) {
@@ -509,89 +604,149 @@ extern "C" int gn_affinity_topk_f32(const float* f, float* corr, float* const* H
   return gn_check_launch();
 }
 
-extern "C" int gn_node2edge_f32(const float* xp, const float* pq, const float* H, const float* w2, float b2,
-                                float* edges, int B, int N, int E, gn_stream_t stream) {
-  GN_REQUIRE_PTR(xp);
-  GN_REQUIRE_PTR(pq);
-  GN_REQUIRE_PTR(w2);
-  GN_REQUIRE_PTR(edges);
-  if (B <= 0 || N <= 0 || E <= 0) return GN_ERR_SHAPE;
-  if (H == nullptr && (long long)E != (long long)N * N) return GN_ERR_SHAPE;
-  const size_t lds = (size_t)(kBlock / 64) * 3 * N * sizeof(float);
-  if (lds > kLdsBudget) return GN_ERR_LDS;
-  const long long total = (long long)B * E;
-  const long long grid = (total + 3) / 4;
-  if (grid > 0x7fffffffLL) return GN_ERR_SHAPE;
-  gn_allow_big_lds(node2edge_kernel<false>);
-  gn_allow_big_lds(node2edge_kernel<true>);
-  if (H)
-    hipLaunchKernelGGL((node2edge_kernel<false>), dim3((unsigned)grid), dim3(kBlock), lds, (hipStream_t)stream, xp, pq,
-                       H, w2, b2, edges, N, E, total);
-  else
-    hipLaunchKernelGGL((node2edge_kernel<true>), dim3((unsigned)grid), dim3(kBlock), lds, (hipStream_t)stream, xp, pq,
-                       H, w2, b2, edges, N, E, total);
+static int check_groups(const void* groups, int n) {
+  if (groups == nullptr) return GN_ERR_NULL;
+  if (n < 1 || n > GN_MAX_GROUPS) return GN_ERR_SHAPE;
+  return GN_OK;
+}
+
+extern "C" int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, gn_stream_t stream) {
+  int rc = check_groups(groups, n_groups);
+  if (rc != GN_OK) return rc;
+  if (B <= 0 || N <= 0) return GN_ERR_SHAPE;
+  GroupTable<gn_n2e_group_t> T{};
+  long long waves = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_n2e_group_t& G = groups[g];
+    if (!G.xp || !G.pq || !G.w2 || !G.edges) return GN_ERR_NULL;
+    if (G.E <= 0) return GN_ERR_SHAPE;
+    if (!gn_aligned16(G.xp) || !gn_aligned16(G.edges)) return GN_ERR_ALIGN;
+    if (G.H == nullptr) {
+      if ((long long)G.E != (long long)N * N) return GN_ERR_SHAPE;
+      continue;
+    }
+    T.g[T.n] = G;
+    T.first[T.n] = waves;
+    waves += (long long)B * G.E;
+    ++T.n;
+  }
+  T.first[T.n] = waves;
+  hipStream_t s = (hipStream_t)stream;
+  // pairwise groups: scenes per workgroup so that the staged rows stay <= 32 KiB; edge bands when one
+  // scene alone has many more edges than a workgroup should walk
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_n2e_group_t& G = groups[g];
+    if (G.H != nullptr) continue;
+    const size_t per_scene = (size_t)N * (GN_FEAT + GN_FEAT + 1) * sizeof(float);
+    const size_t fixed = (2 * kBlock + 32) * sizeof(float);
+    if (per_scene + fixed > kLdsBudget) return GN_ERR_LDS;
+    int SG = 1;
+    while (SG < 8 && (size_t)(2 * SG) * per_scene <= 32 * 1024 && (B + 2 * SG - 1) / (2 * SG) >= 512) SG *= 2;
+    const long long edges_per_wg = (long long)SG * N * N;
+    int bands = 1;
+    while (bands < 64 && edges_per_wg / (bands * 2) >= 2048 && (long long)((B + SG - 1) / SG) * bands < 2048)
+      bands *= 2;
+    const size_t lds = (size_t)SG * per_scene + fixed;
+    gn_allow_big_lds(node2edge_pairwise_kernel);
+    hipLaunchKernelGGL(node2edge_pairwise_kernel, dim3(((B + SG - 1) / SG) * bands), dim3(kBlock), lds, s, G, B, N, SG,
+                       bands);
+  }
+  if (T.n > 0) {
+    const size_t lds = (size_t)(kBlock / 64) * 3 * N * sizeof(float);
+    if (lds > kLdsBudget) return GN_ERR_LDS;
+    const long long grid = (waves + 3) / 4;
+    if (grid > 0x7fffffffLL) return GN_ERR_SHAPE;
+    gn_allow_big_lds(node2edge_kernel);
+    hipLaunchKernelGGL(node2edge_kernel, dim3((unsigned)grid), dim3(kBlock), lds, s, T, N);
+  }
   return gn_check_launch();
 }
 
-extern "C" int gn_agg_gather_f32(const float* ori, const float* H, float* eo, int B, int N, int E,
-                                 gn_stream_t stream) {
-  GN_REQUIRE_PTR(ori);
-  GN_REQUIRE_PTR(eo);
-  GN_REQUIRE_ALIGNED(ori);
-  GN_REQUIRE_ALIGNED(eo);
-  if (B <= 0 || N <= 0 || E <= 0) return GN_ERR_SHAPE;
-  if (H == nullptr) {
-    if ((long long)E != (long long)N * N) return GN_ERR_SHAPE;
-    const long long total4 = (long long)B * E * 16;
-    hipLaunchKernelGGL(agg_gather_pairwise_kernel, dim3(capped_grid(total4, kBlock * 4)), dim3(kBlock), 0,
-                       (hipStream_t)stream, ori, eo, N, total4);
-    return gn_check_launch();
+extern "C" int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, int B, int N, gn_stream_t stream) {
+  int rc = check_groups(groups, n_groups);
+  if (rc != GN_OK) return rc;
+  if (B <= 0 || N <= 0) return GN_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  GatherTable T{};
+  int nh = 0, Emax = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_gather_group_t& G = groups[g];
+    if (!G.ori || !G.eo) return GN_ERR_NULL;
+    if (!gn_aligned16(G.ori) || !gn_aligned16(G.eo)) return GN_ERR_ALIGN;
+    if (G.E <= 0) return GN_ERR_SHAPE;
+    if (G.H == nullptr) {
+      if ((long long)G.E != (long long)N * N) return GN_ERR_SHAPE;
+    } else {
+      T.g[nh++] = G;
+      Emax = G.E > Emax ? G.E : Emax;
+    }
   }
-  const size_t ori_b = (size_t)N * GN_FEAT * sizeof(float);
-  if (ori_b + (size_t)N * sizeof(float) > kLdsBudget) return GN_ERR_LDS;
-  int G = 1, TE = E;
-  const size_t per_scene = ori_b + (size_t)E * N * sizeof(float);
-  if (per_scene <= kLdsBudget) {
-    // several scenes per workgroup while the tile stays <= 24 KiB and the grid stays >= 1024
-    while (G < 16 && (size_t)(2 * G) * per_scene <= 24 * 1024 && (B + 2 * G - 1) / (2 * G) >= 1024) G *= 2;
-  } else {
-    TE = (int)((kLdsBudget - ori_b) / ((size_t)N * sizeof(float)));
-    if (TE < 1) return GN_ERR_LDS;
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_gather_group_t& G = groups[g];
+    if (G.H != nullptr) continue;
+    const long long total4 = (long long)B * G.E * 16;
+    hipLaunchKernelGGL(agg_gather_pairwise_kernel, dim3(capped_grid(total4, kBlock * 4)), dim3(kBlock), 0, s, G.ori,
+                       G.eo, N, total4);
   }
-  const size_t lds = (size_t)G * ori_b + (size_t)G * TE * N * sizeof(float);
-  gn_allow_big_lds(agg_gather_kernel);
-  hipLaunchKernelGGL(agg_gather_kernel, dim3((B + G - 1) / G, (E + TE - 1) / TE), dim3(kBlock), lds,
-                     (hipStream_t)stream, ori, H, eo, B, N, E, G, TE);
+  if (nh > 0) {
+    const size_t ori_b = (size_t)N * GN_FEAT * sizeof(float);
+    if (ori_b + (size_t)N * sizeof(float) > kLdsBudget) return GN_ERR_LDS;
+    int G = 1, TE = Emax;
+    const size_t per_scene = ori_b + (size_t)Emax * N * sizeof(float);
+    if (per_scene <= kLdsBudget) {
+      // several scenes per workgroup while the tile stays <= 24 KiB and the grid stays >= 1024
+      while (G < 16 && (size_t)(2 * G) * per_scene <= 24 * 1024 && (long long)((B + 2 * G - 1) / (2 * G)) * nh >= 1024)
+        G *= 2;
+    } else {
+      TE = (int)((kLdsBudget - ori_b) / ((size_t)N * sizeof(float)));
+      if (TE < 1) return GN_ERR_LDS;
+    }
+    const size_t lds = (size_t)G * ori_b + (size_t)G * TE * N * sizeof(float);
+    gn_allow_big_lds(agg_gather_kernel);
+    hipLaunchKernelGGL(agg_gather_kernel, dim3((B + G - 1) / G, (Emax + TE - 1) / TE, nh), dim3(kBlock), lds, s, T, B,
+                       N, G, TE);
+  }
   return gn_check_launch();
 }
 
-extern "C" int gn_agg_scatter_f32(const float* feat, const float* H, const float* ori, float* out, int B, int N, int E,
-                                  float divisor, gn_stream_t stream) {
-  GN_REQUIRE_PTR(feat);
-  GN_REQUIRE_PTR(ori);
-  GN_REQUIRE_PTR(out);
-  GN_REQUIRE_ALIGNED(feat);
-  GN_REQUIRE_ALIGNED(ori);
-  GN_REQUIRE_ALIGNED(out);
-  if (B <= 0 || N <= 0 || E <= 0 || !(divisor != 0.f)) return GN_ERR_SHAPE;
+extern "C" int gn_agg_scatter_f32(const gn_scatter_group_t* groups, int n_groups, int B, int N, float divisor,
+                                  gn_stream_t stream) {
+  int rc = check_groups(groups, n_groups);
+  if (rc != GN_OK) return rc;
+  if (B <= 0 || N <= 0 || !(divisor != 0.f)) return GN_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
   const long long total4 = (long long)B * N * 32;
-  if (H == nullptr) {
-    if ((long long)E != (long long)N * N) return GN_ERR_SHAPE;
-    hipLaunchKernelGGL((agg_scatter_direct_kernel<true>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0,
-                       (hipStream_t)stream, feat, H, ori, out, N, E, total4, divisor);
-    return gn_check_launch();
+  ScatterTable T{};
+  int nh = 0, Emax = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_scatter_group_t& G = groups[g];
+    if (!G.feat || !G.ori || !G.out) return GN_ERR_NULL;
+    if (!gn_aligned16(G.feat) || !gn_aligned16(G.ori) || !gn_aligned16(G.out)) return GN_ERR_ALIGN;
+    if (G.E <= 0) return GN_ERR_SHAPE;
+    if (G.H == nullptr && (long long)G.E != (long long)N * N) return GN_ERR_SHAPE;
   }
-  const size_t per_scene = (size_t)E * (GN_FEAT + N) * sizeof(float);
-  if (per_scene > kLdsBudget / 2) {
-    hipLaunchKernelGGL((agg_scatter_direct_kernel<false>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0,
-                       (hipStream_t)stream, feat, H, ori, out, N, E, total4, divisor);
-    return gn_check_launch();
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_scatter_group_t& G = groups[g];
+    if (G.H == nullptr) {
+      hipLaunchKernelGGL((agg_scatter_direct_kernel<true>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
+                         G.feat, G.H, G.ori, G.out, N, G.E, total4, divisor);
+    } else if ((size_t)G.E * (GN_FEAT + N) * sizeof(float) > kLdsBudget / 2) {
+      hipLaunchKernelGGL((agg_scatter_direct_kernel<false>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
+                         G.feat, G.H, G.ori, G.out, N, G.E, total4, divisor);
+    } else {
+      T.g[nh++] = G;
+      Emax = G.E > Emax ? G.E : Emax;
+    }
   }
-  int G = 1;
-  while (G < 16 && (size_t)(2 * G) * per_scene <= 24 * 1024 && (B + 2 * G - 1) / (2 * G) >= 1024) G *= 2;
-  gn_allow_big_lds(agg_scatter_kernel);
-  hipLaunchKernelGGL(agg_scatter_kernel, dim3((B + G - 1) / G), dim3(kBlock), (size_t)G * per_scene,
-                     (hipStream_t)stream, feat, H, ori, out, B, N, E, G, divisor);
+  if (nh > 0) {
+    const size_t per_scene = (size_t)Emax * (GN_FEAT + N) * sizeof(float);
+    int G = 1;
+    while (G < 16 && (size_t)(2 * G) * per_scene <= 24 * 1024 && (long long)((B + 2 * G - 1) / (2 * G)) * nh >= 1024)
+      G *= 2;
+    gn_allow_big_lds(agg_scatter_kernel);
+    hipLaunchKernelGGL(agg_scatter_kernel, dim3((B + G - 1) / G, nh), dim3(kBlock), (size_t)G * per_scene, s, T, B, N,
+                       G, Emax, divisor);
+  }
   return gn_check_launch();
 }
 

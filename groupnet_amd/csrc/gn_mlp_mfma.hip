@@ -178,48 +178,61 @@ __device__ __forceinline__ RowBlock row_block(int rows, int block_index) {
 }
 __device__ __forceinline__ int wave_id() { return gn_uniform((int)(threadIdx.x >> 6)); }
 
+// ---- group tables (kernel arguments, by value) -------------------------------------------------
+// blockIdx -> (group, workgroup inside the group).  Groups with equal work use blockIdx.y; ragged ones a
+// prefix table in workgroup units, so a workgroup never straddles two groups and the lookup is scalar.
+template <typename G>
+struct GroupTable {
+  G g[GN_MAX_GROUPS];
+  int first_wg[GN_MAX_GROUPS + 1];
+  int n;
+};
+template <typename G>
+__device__ __forceinline__ int find_group(const GroupTable<G>& t, int wg) {
+  int g = 0;
+  while (g + 1 < t.n && wg >= t.first_wg[g + 1]) ++g;
+  return gn_uniform(g);
+}
+
 // ---- A3 first half: x' = MLP(64->256->64)(x); pq = x' Wpq^T + bpq -----------------------------
-// W = [W0 (256x64) | W1 (64x256) | Wpq (64x64)] packed, bias = [b0 | b1 | bpq].
-__global__ __launch_bounds__(256) void node_mlp_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                       const float* __restrict__ bias, float* __restrict__ xp,
-                                                       float* __restrict__ pq, int rows) {
+// W = [W0 (256x64) | W1 (64x256) | Wpq (64x64)] packed, bias = [b0 | b1 | bpq].  blockIdx.y = group.
+__global__ __launch_bounds__(256) void node_mlp_kernel(GroupTable<gn_node_group_t> T, int rows) {
   const int blk = blockIdx.x * 4 + wave_id();
   if (blk * 32 >= rows) return;  // whole wave past the end
+  const gn_node_group_t G = T.g[blockIdx.y];
   const RowBlock rb = row_block(rows, blk);
   Chain c;
-  chain_begin(c, W, bias, rb.lane);
+  chain_begin(c, G.W, G.bias, rb.lane);
   f32x16 in[2], hid[8], o1[2], o2[2];
-  load_rows<2>(x, GN_FEAT, rb.row_ld, rb.h, in);
+  load_rows<2>(G.x, GN_FEAT, rb.row_ld, rb.h, in);
   chain_linear<8, 2, true>(c, in, hid);
   chain_linear<2, 8, false>(c, hid, o1);
-  store_rows<2>(xp, GN_FEAT, rb.row, rb.h, rb.live, o1);
+  store_rows<2>(G.xp, GN_FEAT, rb.row, rb.h, rb.live, o1);
   chain_linear<2, 2, false>(c, o1, o2, true);
-  store_rows<2>(pq, GN_FEAT, rb.row, rb.h, rb.live, o2);
+  store_rows<2>(G.pq, GN_FEAT, rb.row, rb.h, rb.live, o2);
 }
 
 // ---- A4: z = MLP(64->128->64); [dist|fac] heads; gumbel softmax; sigmoid ------------------------
 // W = [Wi0 (128x64) | Wi1 (64x128) | Wd0 (256x64) | Wd1 (32x256)] packed, bias likewise.
-__global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(const float* __restrict__ edges,
-                                                              const float* __restrict__ U,
-                                                              const float* __restrict__ W,
-                                                              const float* __restrict__ bias,
-                                                              float* __restrict__ edge_feat, float* __restrict__ dist,
-                                                              int rows, int K, float tau, unsigned long long seed,
-                                                              unsigned long long offset,
+__global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge_group_t> T, float tau,
+                                                              unsigned long long seed,
                                                               const unsigned long long* __restrict__ offset_dev) {
-  const int blk = blockIdx.x * 4 + wave_id();
+  const int gi = find_group(T, blockIdx.x);
+  const gn_edge_group_t G = T.g[gi];
+  const int rows = G.rows, K = G.K;
+  const int blk = (blockIdx.x - T.first_wg[gi]) * 4 + wave_id();
   if (blk * 32 >= rows) return;
   const RowBlock rb = row_block(rows, blk);
   Chain c;
-  chain_begin(c, W, bias, rb.lane);
+  chain_begin(c, G.W, G.bias, rb.lane);
   f32x16 in[2], h1[4], z[2], h2[8], lg[1];
-  load_rows<2>(edges, GN_FEAT, rb.row_ld, rb.h, in);
+  load_rows<2>(G.edges, GN_FEAT, rb.row_ld, rb.h, in);
   // The uniforms of this lane's features: read from U (issued now, far ahead of the epilogue) or, with
-  // U == NULL, element row*K + f of the Philox stream at `offset` (+ the device counter) — computed on
-  // the VALU after the MFMAs are queued, so it costs no HBM traffic and no extra launch.
+  // U == NULL, element row*K + f of the Philox stream at `philox_offset` (+ the device counter) — computed
+  // on the VALU after the MFMAs are queued, so it costs no HBM traffic and no extra launch.
   float u[8];
-  if (U != nullptr) {
-    const float* urow = U + (size_t)rb.row_ld * K;
+  if (G.U != nullptr) {
+    const float* urow = G.U + (size_t)rb.row_ld * K;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int f = feat_of(r, rb.h);
@@ -231,8 +244,9 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(const float* __res
   chain_linear<8, 2, true>(c, z, h2);
   chain_linear<1, 8, false>(c, h2, lg, true);
 
-  if (U == nullptr) {
-    const unsigned long long base = offset + (offset_dev ? *offset_dev : 0ull) + (unsigned long long)rb.row_ld * K;
+  if (G.U == nullptr) {
+    const unsigned long long base =
+        G.philox_offset + (offset_dev ? *offset_dev : 0ull) + (unsigned long long)rb.row_ld * K;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int f = feat_of(r, rb.h);
@@ -263,8 +277,8 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(const float* __res
   facv += __shfl_xor(facv, 32, GN_WAVE);  // exactly one of the two lanes holds it, the other has 0
   const float sig = 1.f / (1.f + expf(-facv));
   if (rb.live) {
-    float* drow = dist + (size_t)rb.row * K;
-    float* frow = edge_feat + (size_t)rb.row * K;
+    float* drow = G.dist + (size_t)rb.row * K;
+    float* frow = G.edge_feat + (size_t)rb.row * K;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int f = feat_of(r, rb.h);
@@ -279,34 +293,41 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(const float* __res
 
 // ---- A5 typed MLP: feat = sum_k ef[:,k] * (W2k relu(W1k eo + b1k) + b2k) --------------------------
 // W = for each type k: [W1k (128x64) | W2k (64x128)] packed (64 steps per type); b1 (K,128); b2 (K,64).
-// KT = number of edge types when known at compile time (6: pairwise module, 10: hyper module — the two
-// get distinct kernel names, which keeps their rocprof rows apart), 0 = runtime K.
-// KSPLIT = 1: every wave owns a 32-row block and walks all K types.
-// KSPLIT = 4: the 4 waves of a workgroup share ONE row block, wave w takes types w, w+4, ... and the
-//             partial sums meet in LDS — 4x shorter critical path when there are fewer row blocks
-//             than SIMDs (the hyper modules at B*N rows).
+// Two work shapes, chosen per group by the launcher (block-uniform):
+//   whole : every wave owns a 32-row block and walks all K types;
+//   split : the 4 waves of a workgroup share ONE row block, wave w takes types w, w+4, ... and the
+//           partial sums meet in LDS — a 4x shorter critical path when a group has fewer row blocks
+//           than the chip has SIMDs (the hyper modules at B*N rows).
 constexpr int kTypeSteps = 64;
-template <int KT, int KSPLIT>
-__global__ __launch_bounds__(256) void agg_mlp_kernel(const float* __restrict__ eo, const float* __restrict__ ef,
-                                                      const float* __restrict__ W, const float* __restrict__ b1,
-                                                      const float* __restrict__ b2, float* __restrict__ feat,
-                                                      int rows, int K_rt) {
-  const int K = KT > 0 ? KT : K_rt;
+struct AggGroup {
+  gn_agg_group_t a;
+  int split;  // 0 = whole, 1 = split
+};
+__global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
+  __shared__ float part[4][32][64];  // split mode only: [wave][register 0..31][lane]
+  const int gi = find_group(T, blockIdx.x);
+  const gn_agg_group_t G = T.g[gi].a;
+  const bool split = T.g[gi].split != 0;
+  const int rows = G.rows, K = G.K;
   const int wave = wave_id();
-  const int blk = KSPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
-  if (KSPLIT == 1 && blk * 32 >= rows) return;
+  const int wg = blockIdx.x - T.first_wg[gi];
+  const int blk = split ? wg : wg * 4 + wave;
+  if (!split && blk * 32 >= rows) return;
   const RowBlock rb = row_block(rows, blk);
   const int lane = rb.lane, h = rb.h;
   f32x16 in[2], hid[4], out[2];
-  load_rows<2>(eo, GN_FEAT, rb.row_ld, h, in);
+  load_rows<2>(G.eo, GN_FEAT, rb.row_ld, h, in);
 #pragma unroll
   for (int o = 0; o < 2; ++o)
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[o][r] = 0.f;
-  const float* efrow = ef + (size_t)rb.row_ld * K;
-  const f32x4* Wl = reinterpret_cast<const f32x4*>(W) + lane;
+  const float* efrow = G.edge_feat + (size_t)rb.row_ld * K;
+  const f32x4* Wl = reinterpret_cast<const f32x4*>(G.W) + lane;
+  const float* b1 = G.b1;
+  const float* b2 = G.b2;
+  const int kstride = split ? 4 : 1;
 
-  int k = KSPLIT == 1 ? 0 : wave;
+  int k = split ? wave : 0;
   if (k < K) {
     WRing ring;
     ring_prime(ring, Wl + (size_t)k * kTypeSteps * kStep);
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(const float* __restrict__ 
     float b2f1 = h == 0 ? b2[k * 64 + 32 + (lane & 31)] : 0.f;
 #pragma unroll 1
     while (k < K) {
-      const int kn = k + KSPLIT;
+      const int kn = k + kstride;
       const int kc = kn < K ? kn : k;  // what the run-ahead loads target (valid memory either way)
       const f32x4* base = Wl + (size_t)k * kTypeSteps * kStep;
       const f32x4* base_next = Wl + (size_t)kc * kTypeSteps * kStep;
@@ -345,48 +366,45 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(const float* __restrict__ 
       k = kn;
     }
   }
-  if constexpr (KSPLIT == 1) {
-    store_rows<2>(feat, GN_FEAT, rb.row, h, rb.live, out);
-  } else {
-    static_assert(KSPLIT == 4, "the LDS reduction is written for 4 waves");
-    // partial sums of the 4 waves meet in LDS: [wave][register 0..31][lane]
-    __shared__ float part[4][32][64];
+  if (!split) {
+    store_rows<2>(G.feat, GN_FEAT, rb.row, h, rb.live, out);
+    return;
+  }
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+  for (int o = 0; o < 2; ++o)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) part[wave][16 * o + r][lane] = out[o][r];
-    __syncthreads();
-    // wave w finishes registers 8w .. 8w+7  (tile o = w >> 1, q = 2*(w&1) and 2*(w&1)+1)
-    if (rb.live) {
-      float* p = feat + (size_t)rb.row * GN_FEAT + 4 * h;
+    for (int r = 0; r < 16; ++r) part[wave][16 * o + r][lane] = out[o][r];
+  __syncthreads();
+  // wave w finishes registers 8w .. 8w+7  (tile o = w >> 1, q = 2*(w&1) and 2*(w&1)+1)
+  if (rb.live) {
+    float* p = G.feat + (size_t)rb.row * GN_FEAT + 4 * h;
 #pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        f32x4 v;
+    for (int qq = 0; qq < 2; ++qq) {
+      f32x4 v;
 #pragma unroll
-        for (int cidx = 0; cidx < 4; ++cidx) {
-          const int reg = 8 * wave + 4 * qq + cidx;
-          v[cidx] = (part[0][reg][lane] + part[1][reg][lane]) + (part[2][reg][lane] + part[3][reg][lane]);
-        }
-        const int o = wave >> 1, q = 2 * (wave & 1) + qq;
-        *reinterpret_cast<f32x4*>(p + 32 * o + 8 * q) = v;
+      for (int cidx = 0; cidx < 4; ++cidx) {
+        const int reg = 8 * wave + 4 * qq + cidx;
+        v[cidx] = (part[0][reg][lane] + part[1][reg][lane]) + (part[2][reg][lane] + part[3][reg][lane]);
       }
+      const int o = wave >> 1, q = 2 * (wave & 1) + qq;
+      *reinterpret_cast<f32x4*>(p + 32 * o + 8 * q) = v;
     }
   }
 }
 
 // ---- A6 / generic: y = W1 relu(W0 x + b0) + b1, output tiles streamed -----------------------------
 // W = [W0 (dh x din) | W1 (dout x dh)] packed; bias = [b0 (dh) | b1 padded to a multiple of 32].
+// blockIdx.y = group.
 template <int IT, int HT>
-__global__ __launch_bounds__(256) void mlp2_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                   const float* __restrict__ bias, float* __restrict__ y, int rows,
-                                                   int dout, int ldy) {
+__global__ __launch_bounds__(256) void mlp2_kernel(GroupTable<gn_mlp2_group_t> T, int rows, int dout, int ldy) {
   const int blk = blockIdx.x * 4 + wave_id();
   if (blk * 32 >= rows) return;
+  const gn_mlp2_group_t G = T.g[blockIdx.y];
   const RowBlock rb = row_block(rows, blk);
   Chain c;
-  chain_begin(c, W, bias, rb.lane);
+  chain_begin(c, G.W, G.bias, rb.lane);
   f32x16 in[IT], hid[HT];
-  load_rows<IT>(x, IT * 32, rb.row_ld, rb.h, in);
+  load_rows<IT>(G.x, IT * 32, rb.row_ld, rb.h, in);
   chain_linear<HT, IT, true>(c, in, hid);
   const int OT = (dout + 31) >> 5;
   constexpr int S = 4 * HT;
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(256) void mlp2_kernel(const float* __restrict__ x, 
     c.w += S * kStep;
     c.b += 32;
     if (rb.live) {
-      float* p = y + (size_t)rb.row * ldy;
+      float* p = G.y + (size_t)rb.row * ldy;
       if (((dout | ldy) & 3) == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -422,6 +440,22 @@ __global__ __launch_bounds__(256) void mlp2_kernel(const float* __restrict__ x, 
 
 inline int row_grid(int rows) { return (rows + 127) / 128; }  // 4 waves x 32 rows per block
 
+inline int check_groups(const void* groups, int n) {
+  if (groups == nullptr) return GN_ERR_NULL;
+  if (n < 1 || n > GN_MAX_GROUPS) return GN_ERR_SHAPE;
+  return GN_OK;
+}
+#define GN_CHECK(expr)            \
+  do {                            \
+    const int rc_ = (expr);       \
+    if (rc_ != GN_OK) return rc_; \
+  } while (0)
+inline int need(const void* p, bool aligned) {
+  if (p == nullptr) return GN_ERR_NULL;
+  if (aligned && !gn_aligned16(p)) return GN_ERR_ALIGN;
+  return GN_OK;
+}
+
 }  // namespace
 
 extern "C" size_t gn_packed_elems(int out_features, int in_features) {
@@ -443,81 +477,97 @@ extern "C" int gn_pack_linear_f32(const float* W, float* Wp, int out_features, i
   return gn_check_launch();
 }
 
-extern "C" int gn_node_mlp_f32(const float* x, const float* W, const float* bias, float* xp, float* pq, int rows,
-                               gn_stream_t stream) {
-  const void* ptrs[] = {x, W, bias, xp, pq};
-  for (const void* p : ptrs) {
-    GN_REQUIRE_PTR(p);
-    GN_REQUIRE_ALIGNED(p);
-  }
+extern "C" int gn_node_mlp_f32(const gn_node_group_t* groups, int n_groups, int rows, gn_stream_t stream) {
+  GN_CHECK(check_groups(groups, n_groups));
   if (rows <= 0) return GN_ERR_SHAPE;
-  hipLaunchKernelGGL(node_mlp_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, W, bias, xp, pq,
-                     rows);
-  return gn_check_launch();
-}
-
-extern "C" int gn_edge_mlp_gumbel_f32(const float* edges, const float* U, const float* W, const float* bias,
-                                      float* edge_feat, float* dist, int rows, int K, float tau,
-                                      unsigned long long seed, unsigned long long offset,
-                                      const unsigned long long* offset_dev, gn_stream_t stream) {
-  const void* ptrs[] = {edges, W, bias, edge_feat, dist};
-  for (const void* p : ptrs) GN_REQUIRE_PTR(p);
-  const void* al[] = {edges, W, bias};
-  for (const void* p : al) GN_REQUIRE_ALIGNED(p);
-  if (rows <= 0 || K < 1 || K > 15 || !(tau > 0.f)) return GN_ERR_SHAPE;
-  hipLaunchKernelGGL(edge_mlp_gumbel_kernel, dim3(row_grid(rows)), dim3(256), 0, (hipStream_t)stream, edges, U, W,
-                     bias, edge_feat, dist, rows, K, tau, seed, offset, offset_dev);
-  return gn_check_launch();
-}
-
-extern "C" int gn_agg_mlp_f32(const float* eo, const float* edge_feat, const float* W, const float* b1,
-                              const float* b2, float* feat, int rows, int K, gn_stream_t stream) {
-  const void* ptrs[] = {eo, edge_feat, W, b1, b2, feat};
-  for (const void* p : ptrs) GN_REQUIRE_PTR(p);
-  const void* al[] = {eo, W, b1, feat};
-  for (const void* p : al) GN_REQUIRE_ALIGNED(p);
-  if (rows <= 0 || K < 1 || K > GN_MAX_TYPES) return GN_ERR_SHAPE;
-  hipStream_t s = (hipStream_t)stream;
-  const int blocks32 = (rows + 31) / 32;
-  const dim3 block(256);
-  // fewer row blocks than half the chip's 1024 SIMDs: split the types over the waves of a workgroup
-  if (blocks32 <= 512 && K >= 4) {
-    const dim3 grid(blocks32);
-    if (K == 6)
-      hipLaunchKernelGGL((agg_mlp_kernel<6, 4>), grid, block, 0, s, eo, edge_feat, W, b1, b2, feat, rows, K);
-    else if (K == 10)
-      hipLaunchKernelGGL((agg_mlp_kernel<10, 4>), grid, block, 0, s, eo, edge_feat, W, b1, b2, feat, rows, K);
-    else
-      hipLaunchKernelGGL((agg_mlp_kernel<0, 4>), grid, block, 0, s, eo, edge_feat, W, b1, b2, feat, rows, K);
-  } else {
-    const dim3 grid(row_grid(rows));
-    if (K == 6)
-      hipLaunchKernelGGL((agg_mlp_kernel<6, 1>), grid, block, 0, s, eo, edge_feat, W, b1, b2, feat, rows, K);
-    else if (K == 10)
-      hipLaunchKernelGGL((agg_mlp_kernel<10, 1>), grid, block, 0, s, eo, edge_feat, W, b1, b2, feat, rows, K);
-    else
-      hipLaunchKernelGGL((agg_mlp_kernel<0, 1>), grid, block, 0, s, eo, edge_feat, W, b1, b2, feat, rows, K);
+  GroupTable<gn_node_group_t> T{};
+  T.n = n_groups;
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_node_group_t& G = groups[g];
+    const void* ptrs[] = {G.x, G.W, G.bias, G.xp, G.pq};
+    for (const void* p : ptrs) GN_CHECK(need(p, true));
+    T.g[g] = G;
   }
+  hipLaunchKernelGGL(node_mlp_kernel, dim3(row_grid(rows), n_groups), dim3(256), 0, (hipStream_t)stream, T, rows);
   return gn_check_launch();
 }
 
-extern "C" int gn_mlp2_f32(const float* x, const float* W, const float* bias, float* y, int rows, int din, int dh,
-                           int dout, int ldy, gn_stream_t stream) {
-  const void* ptrs[] = {x, W, bias, y};
-  for (const void* p : ptrs) GN_REQUIRE_PTR(p);
-  const void* al[] = {x, W, bias};
-  for (const void* p : al) GN_REQUIRE_ALIGNED(p);
+extern "C" int gn_edge_mlp_gumbel_f32(const gn_edge_group_t* groups, int n_groups, float tau,
+                                      unsigned long long seed, const unsigned long long* offset_dev,
+                                      gn_stream_t stream) {
+  GN_CHECK(check_groups(groups, n_groups));
+  if (!(tau > 0.f)) return GN_ERR_SHAPE;
+  GroupTable<gn_edge_group_t> T{};
+  T.n = n_groups;
+  int wg = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_edge_group_t& G = groups[g];
+    GN_CHECK(need(G.edges, true));
+    GN_CHECK(need(G.W, true));
+    GN_CHECK(need(G.bias, true));
+    GN_CHECK(need(G.edge_feat, false));
+    GN_CHECK(need(G.dist, false));
+    if (G.rows <= 0 || G.K < 1 || G.K > 15) return GN_ERR_SHAPE;
+    T.g[g] = G;
+    T.first_wg[g] = wg;
+    wg += row_grid(G.rows);
+  }
+  T.first_wg[n_groups] = wg;
+  hipLaunchKernelGGL(edge_mlp_gumbel_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, T, tau, seed, offset_dev);
+  return gn_check_launch();
+}
+
+extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream) {
+  GN_CHECK(check_groups(groups, n_groups));
+  GroupTable<AggGroup> T{};
+  T.n = n_groups;
+  int wg = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_agg_group_t& G = groups[g];
+    GN_CHECK(need(G.eo, true));
+    GN_CHECK(need(G.W, true));
+    GN_CHECK(need(G.b1, true));
+    GN_CHECK(need(G.feat, true));
+    GN_CHECK(need(G.edge_feat, false));
+    GN_CHECK(need(G.b2, false));
+    if (G.rows <= 0 || G.K < 1 || G.K > GN_MAX_TYPES) return GN_ERR_SHAPE;
+    const int blocks32 = (G.rows + 31) / 32;
+    // a group with fewer row blocks than half the chip's 1024 SIMDs: split the types over 4 waves
+    const bool split = blocks32 <= 512 && G.K >= 4;
+    T.g[g].a = G;
+    T.g[g].split = split ? 1 : 0;
+    T.first_wg[g] = wg;
+    wg += split ? blocks32 : row_grid(G.rows);
+  }
+  T.first_wg[n_groups] = wg;
+  hipLaunchKernelGGL(agg_mlp_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, T);
+  return gn_check_launch();
+}
+
+extern "C" int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
+                           gn_stream_t stream) {
+  GN_CHECK(check_groups(groups, n_groups));
   if (rows <= 0 || dout <= 0 || ldy < dout) return GN_ERR_SHAPE;
-  const dim3 grid(row_grid(rows)), block(256);
+  GroupTable<gn_mlp2_group_t> T{};
+  T.n = n_groups;
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_mlp2_group_t& G = groups[g];
+    GN_CHECK(need(G.x, true));
+    GN_CHECK(need(G.W, true));
+    GN_CHECK(need(G.bias, true));
+    GN_CHECK(need(G.y, false));
+    T.g[g] = G;
+  }
+  const dim3 grid(row_grid(rows), n_groups), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (din == 64 && dh == 128)
-    hipLaunchKernelGGL((mlp2_kernel<2, 4>), grid, block, 0, s, x, W, bias, y, rows, dout, ldy);
+    hipLaunchKernelGGL((mlp2_kernel<2, 4>), grid, block, 0, s, T, rows, dout, ldy);
   else if (din == 64 && dh == 256)
-    hipLaunchKernelGGL((mlp2_kernel<2, 8>), grid, block, 0, s, x, W, bias, y, rows, dout, ldy);
+    hipLaunchKernelGGL((mlp2_kernel<2, 8>), grid, block, 0, s, T, rows, dout, ldy);
   else if (din == 128 && dh == 128)
-    hipLaunchKernelGGL((mlp2_kernel<4, 4>), grid, block, 0, s, x, W, bias, y, rows, dout, ldy);
+    hipLaunchKernelGGL((mlp2_kernel<4, 4>), grid, block, 0, s, T, rows, dout, ldy);
   else if (din == 128 && dh == 256)
-    hipLaunchKernelGGL((mlp2_kernel<4, 8>), grid, block, 0, s, x, W, bias, y, rows, dout, ldy);
+    hipLaunchKernelGGL((mlp2_kernel<4, 8>), grid, block, 0, s, T, rows, dout, ldy);
   else
     return GN_ERR_SHAPE;
   return gn_check_launch();

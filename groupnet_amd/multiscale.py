@@ -8,9 +8,9 @@ agent embedding and concatenating the per-scale features (model/GroupNet_nba.py:
     new_H = cat(H_1, H_2, ...) on dim 1                         :296,299
 
 MI355X-first choices: affinity and the incidence of EVERY scale come from one fused launch
-(corr never makes a second trip through HBM); the 1+S modules are independent given (f, corr, H_s),
-so they are issued on separate HIP streams and overlap on the 256 CUs (the hyper modules have only
-B*N edge rows each and would leave most of the chip idle if serialised behind one another).
+(corr never makes a trip through HBM at all); the 1+S modules are independent given (f, H_s), so
+each stage of all of them is ONE grouped launch (the hyper modules have only B*N edge rows each
+and would leave most of the 256 CUs idle if launched one behind the other).
 """
 from __future__ import annotations
 
@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .MS_HGNN_batch import MS_HGNN_hyper, MS_HGNN_oridinary, _NoiseState, _check_forward_only
+from .MS_HGNN_batch import MS_HGNN_hyper, MS_HGNN_oridinary, _check_forward_only, run_message_passing
 
 Tensor = torch.Tensor
 
@@ -34,7 +34,7 @@ class MultiScaleHGNN(nn.Module):
     """
 
     def __init__(self, hyper_scales: Sequence[int] = (2, 5, 11), h_dim: int = 64, nmp_layers: int = 1,
-                 concurrent: bool = True):
+                 grouped: bool = True):
         super().__init__()
         if not 0 <= len(hyper_scales) <= 8:
             raise ValueError("0..8 scales")
@@ -46,8 +46,7 @@ class MultiScaleHGNN(nn.Module):
         self.interaction_hyper = nn.ModuleList(
             MS_HGNN_hyper(embedding_dim=h_dim, h_dim=h_dim, mlp_dim=64, bottleneck_dim=h_dim, batch_norm=0,
                           nmp_layers=nmp_layers, scale=s) for s in self.hyper_scales)
-        self.concurrent = concurrent
-        self._streams: List[torch.cuda.Stream] = []
+        self.grouped = grouped
 
     @property
     def out_features(self) -> int:
@@ -59,11 +58,6 @@ class MultiScaleHGNN(nn.Module):
         for s in self.hyper_scales:
             out.append((B, 1 if s == N else N, 10))
         return out
-
-    def _side_streams(self, n: int, device) -> List[torch.cuda.Stream]:
-        if len(self._streams) < n or (self._streams and self._streams[0].device != device):
-            self._streams = [torch.cuda.Stream(device=device) for _ in range(n)]
-        return self._streams[:n]
 
     def forward(self, f: Tensor, noise_u: Optional[Sequence] = None) -> Tuple[Tensor, Optional[Tensor]]:
         """``noise_u``: optional list with one entry per module (pairwise first), each a tensor or a
@@ -79,24 +73,17 @@ class MultiScaleHGNN(nn.Module):
             noise_u = [[_draw_uniform(shp, f.device) for _ in range(nmp)] for shp in self.noise_shapes(B, N)]
         elif len(noise_u) != 1 + S:
             raise ValueError(f"noise_u: need {1 + S} entries (pairwise + one per scale)")
-        corr, Hs = (ops.affinity_topk(f, self.hyper_scales) if S else (None, []))
+        corr, Hs = (ops.affinity_topk(f, self.hyper_scales, want_corr=False) if S else (None, []))
         final = torch.empty((B, N, self.out_features), dtype=f.dtype, device=f.device)
         final[..., :D].copy_(f)
         cols = [final[..., D * (1 + i):D * (2 + i)] for i in range(1 + S)]   # written in place by the last MLP
-        main = torch.cuda.current_stream(f.device)
-        if self.concurrent and S > 0:
-            side = self._side_streams(S, f.device)
-            for st in side:
-                st.wait_stream(main)
-            for i, (mod, H, st) in enumerate(zip(self.interaction_hyper, Hs, side)):
-                with torch.cuda.stream(st):
-                    mod(f, corr, noise_u=noise_u[1 + i], H=H, out=cols[1 + i])
-            self.interaction(f, noise_u=noise_u[0], out=cols[0])
-            for st in side:
-                main.wait_stream(st)
+        mods = [self.interaction, *self.interaction_hyper]
+        if self.grouped:
+            # every stage of the 1+S modules in ONE launch: launches always carry enough workgroups
+            # to fill the chip, and nothing depends on how streams map to hardware queues
+            run_message_passing(mods, [f] * (1 + S), [None, *Hs], list(noise_u), cols)
         else:
-            self.interaction(f, noise_u=noise_u[0], out=cols[0])
-            for i, (mod, H) in enumerate(zip(self.interaction_hyper, Hs)):
-                mod(f, corr, noise_u=noise_u[1 + i], H=H, out=cols[1 + i])
+            for m, H, u, c in zip(mods, [None, *Hs], noise_u, cols):
+                run_message_passing([m], [f], [H], [u], [c])
         new_H = torch.cat(Hs, dim=1) if S else None
         return final, new_H

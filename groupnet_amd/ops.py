@@ -134,35 +134,64 @@ def bias_stream(biases: Sequence[Tensor]) -> Tensor:
     return torch.cat(parts).contiguous()
 
 
+def _groups(n: int) -> None:
+    if not 1 <= n <= _lib.MAX_GROUPS:
+        raise ValueError(f"1..{_lib.MAX_GROUPS} groups per launch, got {n}")
+
+
+def node_mlp_grouped(items: Sequence[Tuple[Tensor, dict]]) -> List[Tuple[Tensor, Tensor]]:
+    """One launch for several modules: items = [(x (B,N,64), pk{"W","bias"})] with equal shapes;
+    returns [(x', pq)]."""
+    _groups(len(items))
+    x0 = _req(items[0][0], "x", (None, None, FEAT))
+    rows = x0.shape[0] * x0.shape[1]
+    arr = (_lib.NodeGroup * len(items))()
+    outs = []
+    for g, (x, pk) in enumerate(items):
+        _req(x, "x", tuple(x0.shape))
+        _same_device(x0, x)
+        xp, pq = torch.empty_like(x), torch.empty_like(x)
+        arr[g] = _lib.NodeGroup(x.data_ptr(), pk["W"].data_ptr(), pk["bias"].data_ptr(), xp.data_ptr(), pq.data_ptr())
+        outs.append((xp, pq))
+    with torch.cuda.device(x0.device):
+        check(load().gn_node_mlp_f32(arr, len(items), rows, stream_handle()), "gn_node_mlp_f32")
+    return outs
+
+
 def node_mlp(x: Tensor, pk: dict) -> Tuple[Tensor, Tensor]:
     """x (B,N,64) -> x' = MLP_{64->256->64}(x), pq = x' Wpq^T + bpq.  pk: {"W": stream, "bias": stream}."""
-    _req(x, "x", (None, None, FEAT))
-    rows = x.shape[0] * x.shape[1]
-    xp = torch.empty_like(x)
-    pq = torch.empty_like(x)
-    with torch.cuda.device(x.device):
-        check(load().gn_node_mlp_f32(_ptr(x), _ptr(pk["W"]), _ptr(pk["bias"]), _ptr(xp), _ptr(pq), rows,
-                                     stream_handle()), "gn_node_mlp_f32")
-    return xp, pq
+    return node_mlp_grouped([(x, pk)])[0]
+
+
+def node2edge_grouped(items: Sequence[Tuple[Tensor, Tensor, Optional[Tensor], Tensor, float]]) -> List[Tensor]:
+    """items = [(xp, pq, H or None, w2, b2)] over the same (B, N); returns [edges (B,E,64)].
+    H=None selects the implicit pairwise graph (E = N*N)."""
+    _groups(len(items))
+    xp0 = _req(items[0][0], "xp", (None, None, FEAT))
+    B, N, _ = xp0.shape
+    arr = (_lib.N2EGroup * len(items))()
+    outs = []
+    for g, (xp, pq, H, w2, b2) in enumerate(items):
+        _req(xp, "xp", (B, N, FEAT))
+        _req(pq, "pq", (B, N, FEAT))
+        if H is None:
+            E = N * N
+        else:
+            _req(H, "H", (B, None, N))
+            E = H.shape[1]
+        _req(w2, "w2", (32,))
+        _same_device(xp0, xp, pq, H, w2)
+        edges = torch.empty((B, E, FEAT), dtype=xp.dtype, device=xp.device)
+        arr[g] = _lib.N2EGroup(xp.data_ptr(), pq.data_ptr(), 0 if H is None else H.data_ptr(), w2.data_ptr(),
+                               edges.data_ptr(), float(b2), E)
+        outs.append(edges)
+    with torch.cuda.device(xp0.device):
+        check(load().gn_node2edge_f32(arr, len(items), B, N, stream_handle()), "gn_node2edge_f32")
+    return outs
 
 
 def node2edge(xp: Tensor, pq: Tensor, H: Optional[Tensor], w2: Tensor, b2: float) -> Tensor:
-    """edges (B,E,64).  H=None selects the implicit pairwise graph (E = N*N)."""
-    _req(xp, "xp", (None, None, FEAT))
-    _req(pq, "pq", tuple(xp.shape))
-    B, N, _ = xp.shape
-    if H is None:
-        E = N * N
-    else:
-        _req(H, "H", (B, None, N))
-        E = H.shape[1]
-    _req(w2, "w2", (32,))
-    _same_device(xp, pq, H, w2)
-    edges = torch.empty((B, E, FEAT), dtype=xp.dtype, device=xp.device)
-    with torch.cuda.device(xp.device):
-        check(load().gn_node2edge_f32(_ptr(xp), _ptr(pq), _ptr(H), _ptr(w2), float(b2), _ptr(edges), B, N, E,
-                                      stream_handle()), "gn_node2edge_f32")
-    return edges
+    return node2edge_grouped([(xp, pq, H, w2, b2)])[0]
 
 
 # ---- A4 ------------------------------------------------------------------------------------------
@@ -177,101 +206,182 @@ class PhiloxNoise:
         self.seed, self.offset, self.counter = int(seed) & (2**64 - 1), int(offset), counter
 
 
+def edge_mlp_gumbel_grouped(items: Sequence[Tuple[Tensor, object, dict, int]], tau: float = 0.5
+                            ) -> List[Tuple[Tensor, Tensor]]:
+    """items = [(edges (B,E,64), U tensor (B,E,K) or PhiloxNoise, pk, K)]; returns [(edge_feat, dist)].
+    All PhiloxNoise entries of one call must share seed and counter (one stream per launch)."""
+    _groups(len(items))
+    e0 = items[0][0]
+    arr = (_lib.EdgeGroup * len(items))()
+    outs = []
+    seed, ctr = None, None
+    for g, (edges, U, pk, K) in enumerate(items):
+        _req(edges, "edges", (None, None, FEAT))
+        _same_device(e0, edges)
+        B, E, _ = edges.shape
+        if isinstance(U, PhiloxNoise):
+            if seed is None:
+                seed, ctr = U.seed, U.counter
+            elif (seed, ctr) != (U.seed, U.counter) and not (seed == U.seed and ctr is U.counter):
+                raise ValueError("all PhiloxNoise groups of one launch must share seed and counter")
+            u_ptr, off = 0, U.offset
+        else:
+            _req(U, "noise_u", (B, E, K))
+            _same_device(edges, U)
+            u_ptr, off = U.data_ptr(), 0
+        edge_feat = torch.empty((B, E, K), dtype=edges.dtype, device=edges.device)
+        dist = torch.empty_like(edge_feat)
+        arr[g] = _lib.EdgeGroup(edges.data_ptr(), u_ptr, pk["W"].data_ptr(), pk["bias"].data_ptr(),
+                                edge_feat.data_ptr(), dist.data_ptr(), off, B * E, K)
+        outs.append((edge_feat, dist))
+    with torch.cuda.device(e0.device):
+        check(load().gn_edge_mlp_gumbel_f32(arr, len(items), float(tau), seed or 0, _ptr(ctr), stream_handle()),
+              "gn_edge_mlp_gumbel_f32")
+    return outs
+
+
 def edge_mlp_gumbel(edges: Tensor, U, pk: dict, K: int, tau: float = 0.5) -> Tuple[Tensor, Tensor]:
     """(edge_feat, dist) of MLP_dict_softmax.  `U`: a (B,E,K) tensor of uniforms, or a PhiloxNoise."""
-    _req(edges, "edges", (None, None, FEAT))
-    B, E, _ = edges.shape
-    if isinstance(U, PhiloxNoise):
-        u_ptr, seed, off, ctr = _P(0), U.seed, U.offset, _ptr(U.counter)
-    else:
-        _req(U, "noise_u", (B, E, K))
-        _same_device(edges, U)
-        u_ptr, seed, off, ctr = _ptr(U), 0, 0, _P(0)
-    edge_feat = torch.empty((B, E, K), dtype=edges.dtype, device=edges.device)
-    dist = torch.empty_like(edge_feat)
-    with torch.cuda.device(edges.device):
-        check(load().gn_edge_mlp_gumbel_f32(_ptr(edges), u_ptr, _ptr(pk["W"]), _ptr(pk["bias"]), _ptr(edge_feat),
-                                            _ptr(dist), B * E, K, float(tau), seed, off, ctr, stream_handle()),
-              "gn_edge_mlp_gumbel_f32")
-    return edge_feat, dist
+    return edge_mlp_gumbel_grouped([(edges, U, pk, K)], tau)[0]
 
 
 # ---- A5 ------------------------------------------------------------------------------------------
-def agg_gather(ori: Tensor, H: Optional[Tensor]) -> Tensor:
-    _req(ori, "ori", (None, None, FEAT))
-    B, N, _ = ori.shape
+def _edge_count(H: Optional[Tensor], B: int, N: int) -> int:
     if H is None:
-        E = N * N
-    else:
-        _req(H, "H", (B, None, N))
-        E = H.shape[1]
-        _same_device(ori, H)
-    eo = torch.empty((B, E, FEAT), dtype=ori.dtype, device=ori.device)
-    with torch.cuda.device(ori.device):
-        check(load().gn_agg_gather_f32(_ptr(ori), _ptr(H), _ptr(eo), B, N, E, stream_handle()), "gn_agg_gather_f32")
-    return eo
+        return N * N
+    _req(H, "H", (B, None, N))
+    return H.shape[1]
+
+
+def agg_gather_grouped(items: Sequence[Tuple[Tensor, Optional[Tensor]]]) -> List[Tensor]:
+    """items = [(ori (B,N,64), H (B,E,N) or None)] -> [eo (B,E,64)]."""
+    _groups(len(items))
+    o0 = _req(items[0][0], "ori", (None, None, FEAT))
+    B, N, _ = o0.shape
+    arr = (_lib.GatherGroup * len(items))()
+    outs = []
+    for g, (ori, H) in enumerate(items):
+        _req(ori, "ori", (B, N, FEAT))
+        E = _edge_count(H, B, N)
+        _same_device(o0, ori, H)
+        eo = torch.empty((B, E, FEAT), dtype=ori.dtype, device=ori.device)
+        arr[g] = _lib.GatherGroup(ori.data_ptr(), 0 if H is None else H.data_ptr(), eo.data_ptr(), E)
+        outs.append(eo)
+    with torch.cuda.device(o0.device):
+        check(load().gn_agg_gather_f32(arr, len(items), B, N, stream_handle()), "gn_agg_gather_f32")
+    return outs
+
+
+def agg_gather(ori: Tensor, H: Optional[Tensor]) -> Tensor:
+    return agg_gather_grouped([(ori, H)])[0]
+
+
+def agg_mlp_grouped(items: Sequence[Tuple[Tensor, Tensor, dict, int]]) -> List[Tensor]:
+    """items = [(eo (B,E,64), edge_feat (B,E,K), pk{"W","b1","b2"}, K)] -> [feat (B,E,64)]."""
+    _groups(len(items))
+    e0 = items[0][0]
+    arr = (_lib.AggGroup * len(items))()
+    outs = []
+    flops = 0
+    for g, (eo, edge_feat, pk, K) in enumerate(items):
+        _req(eo, "eo", (None, None, FEAT))
+        B, E, _ = eo.shape
+        _req(edge_feat, "edge_feat", (B, E, K))
+        _same_device(e0, eo, edge_feat)
+        feat = torch.empty_like(eo)
+        arr[g] = _lib.AggGroup(eo.data_ptr(), edge_feat.data_ptr(), pk["W"].data_ptr(), pk["b1"].data_ptr(),
+                               pk["b2"].data_ptr(), feat.data_ptr(), B * E, K)
+        outs.append(feat)
+        flops += B * E * K * (2 * 64 * 128 + 2 * 128 * 64 + 2 * 64)
+    probe = launch_probe
+    with torch.cuda.device(e0.device):
+        if probe is not None:
+            probe("agg_mlp", flops, True)
+        check(load().gn_agg_mlp_f32(arr, len(items), stream_handle()), "gn_agg_mlp_f32")
+        if probe is not None:
+            probe("agg_mlp", flops, False)
+    return outs
 
 
 def agg_mlp(eo: Tensor, edge_feat: Tensor, pk: dict, K: int) -> Tensor:
-    _req(eo, "eo", (None, None, FEAT))
-    B, E, _ = eo.shape
-    _req(edge_feat, "edge_feat", (B, E, K))
-    _same_device(eo, edge_feat)
-    feat = torch.empty_like(eo)
-    probe = launch_probe
-    with torch.cuda.device(eo.device):
-        if probe is not None:
-            probe("agg_mlp", K, B * E, True)
-        check(load().gn_agg_mlp_f32(_ptr(eo), _ptr(edge_feat), _ptr(pk["W"]), _ptr(pk["b1"]), _ptr(pk["b2"]),
-                                    _ptr(feat), B * E, K, stream_handle()), "gn_agg_mlp_f32")
-        if probe is not None:
-            probe("agg_mlp", K, B * E, False)
-    return feat
+    return agg_mlp_grouped([(eo, edge_feat, pk, K)])[0]
+
+
+def agg_scatter_grouped(items: Sequence[Tuple[Tensor, Optional[Tensor], Tensor]], divisor: Optional[float] = None
+                        ) -> List[Tensor]:
+    """items = [(feat (B,E,64), H or None, ori (B,N,64))] -> [cat(H^T feat, ori) / divisor (B,N,128)];
+    divisor defaults to N (edge2node, model/MS_HGNN_batch.py:120,355)."""
+    _groups(len(items))
+    o0 = _req(items[0][2], "ori", (None, None, FEAT))
+    B, N, _ = o0.shape
+    arr = (_lib.ScatterGroup * len(items))()
+    outs = []
+    for g, (feat, H, ori) in enumerate(items):
+        _req(ori, "ori", (B, N, FEAT))
+        E = _edge_count(H, B, N)
+        _req(feat, "feat", (B, E, FEAT))
+        _same_device(o0, feat, ori, H)
+        out = torch.empty((B, N, 2 * FEAT), dtype=ori.dtype, device=ori.device)
+        arr[g] = _lib.ScatterGroup(feat.data_ptr(), 0 if H is None else H.data_ptr(), ori.data_ptr(), out.data_ptr(), E)
+        outs.append(out)
+    with torch.cuda.device(o0.device):
+        check(load().gn_agg_scatter_f32(arr, len(items), B, N, float(N if divisor is None else divisor),
+                                        stream_handle()), "gn_agg_scatter_f32")
+    return outs
 
 
 def agg_scatter(feat: Tensor, H: Optional[Tensor], ori: Tensor, divisor: Optional[float] = None) -> Tensor:
-    """cat(H^T feat, ori) / divisor; divisor defaults to N (edge2node, model/MS_HGNN_batch.py:120,355)."""
-    _req(ori, "ori", (None, None, FEAT))
-    B, N, _ = ori.shape
-    if H is None:
-        E = N * N
-    else:
-        _req(H, "H", (B, None, N))
-        E = H.shape[1]
-    _req(feat, "feat", (B, E, FEAT))
-    _same_device(feat, ori, H)
-    out = torch.empty((B, N, 2 * FEAT), dtype=ori.dtype, device=ori.device)
-    with torch.cuda.device(ori.device):
-        check(load().gn_agg_scatter_f32(_ptr(feat), _ptr(H), _ptr(ori), _ptr(out), B, N, E,
-                                        float(N if divisor is None else divisor), stream_handle()), "gn_agg_scatter_f32")
-    return out
+    return agg_scatter_grouped([(feat, H, ori)], divisor)[0]
 
 
 # ---- A6 ------------------------------------------------------------------------------------------
-def mlp2(x: Tensor, pk: dict, out: Optional[Tensor] = None) -> Tensor:
-    """y = W1 relu(W0 x + b0) + b1 over the last dim of x.  ``out`` may be a last-dim slice of a
-    contiguous tensor (row stride > dout): the kernel writes the column block in place."""
-    din, dh, dout = pk["din"], pk["dh"], pk["dout"]
-    _req(x, "x")
-    if x.shape[-1] != din:
-        raise ValueError(f"x: last dim {x.shape[-1]} != {din}")
-    rows = x.numel() // din
+def _mlp2_out(x: Tensor, dout: int, out: Optional[Tensor]) -> Tuple[Tensor, int]:
     if out is None:
-        out = torch.empty(tuple(x.shape[:-1]) + (dout,), dtype=x.dtype, device=x.device)
-        ldy = dout
-    else:
-        if not (out.is_cuda and out.dtype == torch.float32 and out.device == x.device):
-            raise ValueError("out: must be a float32 tensor on x's device")
-        if tuple(out.shape) != tuple(x.shape[:-1]) + (dout,) or out.stride(-1) != 1:
-            raise ValueError(f"out: expected shape {tuple(x.shape[:-1]) + (dout,)} with unit inner stride")
-        ldy = out.stride(-2) if out.dim() >= 2 else dout
-        for d in range(out.dim() - 2):   # leading dims must be row-contiguous w.r.t. ldy
-            if out.stride(d) != out.stride(d + 1) * out.shape[d + 1]:
-                raise ValueError("out: leading dimensions must be contiguous")
-    with torch.cuda.device(x.device):
-        check(load().gn_mlp2_f32(_ptr(x), _ptr(pk["W"]), _ptr(pk["bias"]), _ptr(out), rows, din, dh, dout, ldy,
-                                 stream_handle()), "gn_mlp2_f32")
-    return out
+        return torch.empty(tuple(x.shape[:-1]) + (dout,), dtype=x.dtype, device=x.device), dout
+    if not (out.is_cuda and out.dtype == torch.float32 and out.device == x.device):
+        raise ValueError("out: must be a float32 tensor on x's device")
+    if tuple(out.shape) != tuple(x.shape[:-1]) + (dout,) or out.stride(-1) != 1:
+        raise ValueError(f"out: expected shape {tuple(x.shape[:-1]) + (dout,)} with unit inner stride")
+    ldy = out.stride(-2) if out.dim() >= 2 else dout
+    for d in range(out.dim() - 2):   # leading dims must be row-contiguous w.r.t. ldy
+        if out.stride(d) != out.stride(d + 1) * out.shape[d + 1]:
+            raise ValueError("out: leading dimensions must be contiguous")
+    return out, ldy
+
+
+def mlp2_grouped(items: Sequence[Tuple[Tensor, dict, Optional[Tensor]]]) -> List[Tensor]:
+    """items = [(x (..., din), pk{"W","bias","din","dh","dout"}, out or None)], same shapes and row
+    stride for every group.  ``out`` may be a last-dim slice of a contiguous tensor (row stride >
+    dout): the kernel writes the column block in place."""
+    _groups(len(items))
+    x0, pk0, _ = items[0]
+    din, dh, dout = pk0["din"], pk0["dh"], pk0["dout"]
+    _req(x0, "x")
+    if x0.shape[-1] != din:
+        raise ValueError(f"x: last dim {x0.shape[-1]} != {din}")
+    rows = x0.numel() // din
+    arr = (_lib.Mlp2Group * len(items))()
+    outs, ld0 = [], None
+    for g, (x, pk, out) in enumerate(items):
+        _req(x, "x", tuple(x0.shape))
+        _same_device(x0, x)
+        if (pk["din"], pk["dh"], pk["dout"]) != (din, dh, dout):
+            raise ValueError("grouped mlp2: every group must have the same layer widths")
+        y, ldy = _mlp2_out(x, dout, out)
+        if ld0 is None:
+            ld0 = ldy
+        elif ldy != ld0:
+            raise ValueError("grouped mlp2: every group must have the same output row stride")
+        arr[g] = _lib.Mlp2Group(x.data_ptr(), pk["W"].data_ptr(), pk["bias"].data_ptr(), y.data_ptr())
+        outs.append(y)
+    with torch.cuda.device(x0.device):
+        check(load().gn_mlp2_f32(arr, len(items), rows, din, dh, dout, ld0, stream_handle()), "gn_mlp2_f32")
+    return outs
+
+
+def mlp2(x: Tensor, pk: dict, out: Optional[Tensor] = None) -> Tensor:
+    """y = W1 relu(W0 x + b0) + b1 over the last dim of x."""
+    return mlp2_grouped([(x, pk, out)])[0]
 
 
 # ---- noise ---------------------------------------------------------------------------------------

@@ -78,26 +78,48 @@ size_t gn_packed_elems(int out_features, int in_features);
 int gn_pack_linear_f32(const float* W, float* Wp, int out_features, int in_features, int ld,
                        int col_offset, gn_stream_t stream);
 
+/* ---- grouped launches --------------------------------------------------------------------
+ * The 1+S modules of one multiscale forward (pairwise + one hyper module per scale) are
+ * independent and differ only in weights, incidence and edge count.  Every stage below
+ * therefore takes an array of `n_groups` descriptors (HOST memory, 1 <= n_groups <=
+ * GN_MAX_GROUPS) and serves all of them with ONE launch, so that a launch always carries
+ * enough workgroups to fill the 256 CUs; a single module is the n_groups == 1 case.
+ * Groups must not alias each other's outputs. */
+#define GN_MAX_GROUPS 10
+
 /* ---- A3 (first half): node MLP + attention projections -----------------------------------
  * x' = MLP_{64->256->64}(x)            (node2edge_start_mlp, MS_HGNN_batch.py:125,358)
  * pq = x' Wpq^T + bpq  (64 wide)       the node-side halves of attention_mlp layer 0
  *                                      (MS_HGNN_batch.py:131-134,362-365), see gn_node2edge_f32.
  * W    = packed images [W0 (256x64) | W1 (64x256) | Wpq (64x64)] back to back (one weight stream,
  *        consumed in this order); bias = [b0 (256) | b1 (64) | bpq (64)].
- * x (rows,64) -> xp (rows,64), pq (rows,64). */
-int gn_node_mlp_f32(const float* x, const float* W, const float* bias, float* xp, float* pq, int rows,
-                    gn_stream_t stream);
+ * x (rows,64) -> xp (rows,64), pq (rows,64) per group. */
+typedef struct {
+  const float* x;
+  const float* W;
+  const float* bias;
+  float* xp;
+  float* pq;
+} gn_node_group_t;
+int gn_node_mlp_f32(const gn_node_group_t* groups, int n_groups, int rows, gn_stream_t stream);
 
 /* ---- A3 (second half): attention-weighted node -> edge pooling ---------------------------
  * Replaces the rest of node2edge, MS_HGNN_batch.py:127-141 / 359-370:
  *   e0 = H x';  att[e,n] = w2 . relu(P_n + (H Qn)_e) + b2  with P = pq[:, :32] (bias folded),
  *   Qn = pq[:, 32:];  W = softmax_n(att * H) * H;  edges = W x'.
- * H == NULL selects the pairwise graph of MS_HGNN_oridinary (E = N*N, edge e = i*N + j has
+ * H == NULL selects the pairwise graph of MS_HGNN_oridinary (E must be N*N; edge e = i*N + j has
  * weight 1 on i and on j, 2 when i == j; MS_HGNN_batch.py:118,124,143-160) without ever
- * materialising it.  xp, pq (B,N,64); H (B,E,N) or NULL; w2 (32 floats, device); b2 scalar
- * passed by value;  edges (B,E,64). */
-int gn_node2edge_f32(const float* xp, const float* pq, const float* H, const float* w2, float b2,
-                     float* edges, int B, int N, int E, gn_stream_t stream);
+ * materialising it.  xp, pq (B,N,64); H (B,E,N) or NULL; w2 (32 floats, device); edges (B,E,64). */
+typedef struct {
+  const float* xp;
+  const float* pq;
+  const float* H;
+  const float* w2;
+  float* edges;
+  float b2;
+  int E;
+} gn_n2e_group_t;
+int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, gn_stream_t stream);
 
 /* ---- A4: per-edge MLPs + Gumbel-softmax edge typing ----------------------------------------
  * Replaces MLP_dict_softmax.forward + gumbel_softmax, MS_HGNN_batch.py:41-53,446-520:
@@ -109,38 +131,76 @@ int gn_node2edge_f32(const float* xp, const float* pq, const float* H, const flo
  * bias = [128 | 64 | 256 | 32] in the same order (bd1: K logits biases, then the factor bias, zeros).
  * edges (rows,64), U (rows,K) uniforms in [0,1) -> edge_feat (rows,K), dist (rows,K).  K <= 15.
  * U == NULL: the uniforms are generated inside the kernel — element row*K + k is element
- * offset (+ *offset_dev if not NULL) + row*K + k of the Philox stream `seed`, exactly what
+ * philox_offset (+ *offset_dev if not NULL) + row*K + k of the Philox stream `seed`, exactly what
  * gn_philox_uniform_f32 would have written into U. */
-int gn_edge_mlp_gumbel_f32(const float* edges, const float* U, const float* W, const float* bias,
-                           float* edge_feat, float* dist, int rows, int K, float tau,
-                           unsigned long long seed, unsigned long long offset,
+typedef struct {
+  const float* edges;
+  const float* U;
+  const float* W;
+  const float* bias;
+  float* edge_feat;
+  float* dist;
+  unsigned long long philox_offset;
+  int rows;
+  int K;
+} gn_edge_group_t;
+int gn_edge_mlp_gumbel_f32(const gn_edge_group_t* groups, int n_groups, float tau, unsigned long long seed,
                            const unsigned long long* offset_dev, gn_stream_t stream);
 
 /* ---- A5: hyperedge aggregation --------------------------------------------------------------
  * gather: eo = H ori            (edge_aggregation.forward, MS_HGNN_batch.py:263)
- * H == NULL: pairwise graph, eo[(i,j)] = ori_i + ori_j.   ori (B,N,64) -> eo (B,E,64). */
-int gn_agg_gather_f32(const float* ori, const float* H, float* eo, int B, int N, int E,
-                      gn_stream_t stream);
+ * H == NULL: pairwise graph (E = N*N), eo[(i,j)] = ori_i + ori_j.   ori (B,N,64) -> eo (B,E,64). */
+typedef struct {
+  const float* ori;
+  const float* H;
+  float* eo;
+  int E;
+} gn_gather_group_t;
+int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, int B, int N, gn_stream_t stream);
+
 /* typed MLP: feat = sum_k edge_feat[:,k] * MLP^k_{64->128->64}(eo)   (MS_HGNN_batch.py:262,264-265)
  * W: for each type k the packed images [agg_mlp[k].layers.0 (128x64) | agg_mlp[k].layers.1 (64x128)],
  * types back to back; b1 (K,128); b2 (K,64).  eo (rows,64), edge_feat (rows,K) -> feat (rows,64). */
-int gn_agg_mlp_f32(const float* eo, const float* edge_feat, const float* W, const float* b1,
-                   const float* b2, float* feat, int rows, int K, gn_stream_t stream);
+typedef struct {
+  const float* eo;
+  const float* edge_feat;
+  const float* W;
+  const float* b1;
+  const float* b2;
+  float* feat;
+  int rows;
+  int K;
+} gn_agg_group_t;
+int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream);
+
 /* scatter: out = cat(H^T feat, ori) / divisor     (MS_HGNN_batch.py:267; divisor = N gives the
  * division of edge2node :120,355, divisor = 1 the bare edge_aggregation.forward).
- * feat (B,E,64), ori (B,N,64) -> out (B,N,128).  H == NULL: pairwise. */
-int gn_agg_scatter_f32(const float* feat, const float* H, const float* ori, float* out, int B, int N,
-                       int E, float divisor, gn_stream_t stream);
+ * feat (B,E,64), ori (B,N,64) -> out (B,N,128).  H == NULL: pairwise (E = N*N). */
+typedef struct {
+  const float* feat;
+  const float* H;
+  const float* ori;
+  float* out;
+  int E;
+} gn_scatter_group_t;
+int gn_agg_scatter_f32(const gn_scatter_group_t* groups, int n_groups, int B, int N, float divisor,
+                       gn_stream_t stream);
 
 /* ---- A6 / generic two-layer MLP ---------------------------------------------------------------
  * y = W1 relu(W0 x + b0) + b1     (MLP.forward with one hidden layer, MS_HGNN_batch.py:220-229;
  * nmp_mlp_end 128->128->bottleneck and nmp_mlps[even] 128->128->64).
- * din in {64,128}, dh in {128,256}, dout >= 1.  W = packed [W0 (dh x din) | W1 (dout x dh)];
- * bias = [b0 (dh) | b1 zero-padded to a multiple of 32].
+ * din in {64,128}, dh in {128,256}, dout >= 1 (the same for every group).
+ * W = packed [W0 (dh x din) | W1 (dout x dh)]; bias = [b0 (dh) | b1 zero-padded to a multiple of 32].
  * x (rows,din) -> y (rows,dout) with row stride ldy >= dout floats (lets the result land in a
  * column block of a wider tensor, e.g. the concatenated per-scale features). */
-int gn_mlp2_f32(const float* x, const float* W, const float* bias, float* y, int rows, int din, int dh,
-                int dout, int ldy, gn_stream_t stream);
+typedef struct {
+  const float* x;
+  const float* W;
+  const float* bias;
+  float* y;
+} gn_mlp2_group_t;
+int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
+                gn_stream_t stream);
 
 /* ---- device noise (build's own; the reference draws torch.rand on the host) --------------------
  * U[i] = Philox4x32-10(counter = (i + offset) / 4, key = seed)[(i + offset) % 4] >> 8, scaled to

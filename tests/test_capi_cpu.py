@@ -44,9 +44,22 @@ def test_null_and_shape_errors_do_not_launch():
     Hs = (P * 1)(16)
     ks = (ctypes.c_int * 1)(12)
     assert lib.gn_topk_incidence_f32(P(16), Hs, ks, 1, 2, 11, P(0)) == -3      # k > N
-    assert lib.gn_mlp2_f32(P(16), P(16), P(16), P(16), 5, 96, 128, 64, 64, P(0)) == -2
-    assert lib.gn_agg_mlp_f32(P(16), P(16), P(16), P(16), P(16), P(16), 5, 17, P(0)) == -2
-    assert lib.gn_node2edge_f32(P(16), P(16), P(0), P(16), 0.0, P(16), 2, 3, 8, P(0)) == -2  # pairwise needs E == N*N
+    # grouped stages: descriptors are validated on the host too
+    g = (_lib.Mlp2Group * 1)(_lib.Mlp2Group(16, 16, 16, 16))
+    assert lib.gn_mlp2_f32(g, 1, 5, 96, 128, 64, 64, P(0)) == -2            # unsupported widths
+    assert lib.gn_mlp2_f32(g, 0, 5, 128, 128, 64, 64, P(0)) == -2           # no groups
+    assert lib.gn_mlp2_f32(g, 11, 5, 128, 128, 64, 64, P(0)) == -2          # > GN_MAX_GROUPS
+    assert lib.gn_mlp2_f32(None, 1, 5, 128, 128, 64, 64, P(0)) == -1
+    a = (_lib.AggGroup * 1)(_lib.AggGroup(16, 16, 16, 16, 16, 16, 5, 17))
+    assert lib.gn_agg_mlp_f32(a, 1, P(0)) == -2                             # K > GN_MAX_TYPES
+    a[0].K, a[0].W = 6, 8
+    assert lib.gn_agg_mlp_f32(a, 1, P(0)) == -4                             # misaligned weight stream
+    n = (_lib.N2EGroup * 1)(_lib.N2EGroup(16, 16, 0, 16, 16, 0.0, 8))
+    assert lib.gn_node2edge_f32(n, 1, 2, 3, P(0)) == -2                     # pairwise needs E == N*N
+    e = (_lib.EdgeGroup * 1)(_lib.EdgeGroup(16, 0, 16, 16, 16, 16, 0, 10, 16))
+    assert lib.gn_edge_mlp_gumbel_f32(e, 1, 0.5, 0, P(0), P(0)) == -2       # K > 15
+    e[0].K = 10
+    assert lib.gn_edge_mlp_gumbel_f32(e, 1, 0.0, 0, P(0), P(0)) == -2       # tau must be > 0
 
 
 def test_state_dict_layout_matches_reference_checkpoints():

@@ -369,14 +369,14 @@ def test_graph_capture_replays():
         assert torch.equal(out, ref2) and not torch.equal(ref, ref2)
 
 
-@pytest.mark.parametrize("concurrent", [False, True])
-def test_multiscale_block_matches_oracle(concurrent):
+@pytest.mark.parametrize("grouped", [False, True])
+def test_multiscale_block_matches_oracle(grouped):
     """The PastEncoder-shaped block (model/GroupNet_nba.py:284-311): fused affinity+top-k, the
-    1+S modules (on side streams when concurrent), features written in place into the concat."""
+    1+S modules (every stage one grouped launch, or module by module), features written in place."""
     from groupnet_amd.multiscale import MultiScaleHGNN
     torch.manual_seed(21)
     scales = [2, 5, 11]
-    blk = MultiScaleHGNN(scales, concurrent=concurrent)
+    blk = MultiScaleHGNN(scales, grouped=grouped)
     sp = {k: v.detach().clone() for k, v in blk.interaction.state_dict().items()}
     shs = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in blk.interaction_hyper]
     blk.to(dev()).eval()
