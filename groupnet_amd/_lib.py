@@ -13,7 +13,7 @@ import threading
 import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgroupnet_hip.so")
+LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
 ABI_VERSION = 4
 
 GN_OK = 0

@@ -21,6 +21,8 @@
 //
 // fp32 MFMA is an exact k-ordered fmaf chain, so results differ from the reference's MKL
 // GEMMs only by summation order (~1e-7 relative).
+#include <stdlib.h>
+
 #include "gn_common.hpp"
 
 namespace {
@@ -102,25 +104,34 @@ __device__ __forceinline__ void ring_prime(WRing& ring, const f32x4* __restrict_
   for (int i = 0; i < kP; ++i) ring.s[i] = p[i * kStep];
 }
 
-// acc += W[tile] . in, the tile being 4*IT consecutive steps at `cur` (this lane's pointer).  On entry
-// the ring holds steps 0..kP-1 of the tile; on exit steps 0..kP-1 of whatever `nxt` points at — the
-// tile consumed next (by default the one that follows in memory).
-template <int IT>
+// acc += W[tile] . in, the tile being 4*IT consecutive steps at `cur` (this lane's pointer).  The ring
+// always holds the next kP steps of the stream; START is the ring slot of the tile's first step (the
+// running step count of the kernel modulo kP — 0 whenever every tile before it was a whole number of
+// ring turns).  `nxt` points at the steps consumed after this tile (by default the ones that follow in
+// memory).  `side(s)` runs right after the MFMAs of step s are issued: VALU work on a PREVIOUS tile's
+// accumulator placed there executes in the shadow of this tile's MFMAs instead of stalling the pipe.
+struct NoSide {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <int IT, int START = 0, typename Side = NoSide>
 __device__ __forceinline__ void mma_tile(const f32x4* __restrict__ cur, const f32x4* __restrict__ nxt, WRing& ring,
-                                         const f32x16 (&in)[IT], f32x16& acc) {
+                                         const f32x16 (&in)[IT], f32x16& acc, Side side = Side()) {
   constexpr int S = 4 * IT;
-  static_assert(S % kP == 0, "a tile must be a whole number of ring turns");
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const int t = s >> 2, q = s & 3;
-    const f32x4 w = ring.s[s % kP];
+    const int slot = (START + s) % kP;
+    const f32x4 w = ring.s[slot];
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], in[t][4 * q + 0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], in[t][4 * q + 1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], in[t][4 * q + 2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], in[t][4 * q + 3], acc, 0, 0, 0);
-    ring.s[s % kP] = (s + kP < S) ? cur[(s + kP) * kStep] : nxt[(s + kP - S) * kStep];
+    side(s);
+    ring.s[slot] = (s + kP < S) ? cur[(s + kP) * kStep] : nxt[(s + kP - S) * kStep];
     // hipcc otherwise sinks the run-ahead load down to its use and collapses the ring to depth 1-2
+#if !defined(GN_EXP_NO_SCHED_BARRIER)
     __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
 
@@ -293,27 +304,42 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge
 
 // ---- A5 typed MLP: feat = sum_k ef[:,k] * (W2k relu(W1k eo + b1k) + b2k) --------------------------
 // W = for each type k: [W1k (128x64) | W2k (64x128)] packed (64 steps per type); b1 (K,128); b2 (K,64).
-// Two work shapes, chosen per group by the launcher (block-uniform):
-//   whole : every wave owns a 32-row block and walks all K types;
-//   split : the 4 waves of a workgroup share ONE row block, wave w takes types w, w+4, ... and the
-//           partial sums meet in LDS — a 4x shorter critical path when a group has fewer row blocks
-//           than the chip has SIMDs (the hyper modules at B*N rows).
+// Work shape, chosen per group by the launcher (block-uniform): `wpr` waves share one 32-row block,
+// wave w of them takes types w, w+wpr, ... and the partial sums meet in LDS.
+//   wpr = 1 : every wave owns a row block and walks all K types (no LDS);
+//   wpr = 2 : the pairwise module (K = 6 -> 3 types per wave): twice as many, half as long work units,
+//             which is what lets the chip's 1024 SIMDs finish together (one 6-type unit is ~47 us);
+//   wpr = 4 : groups with fewer row blocks than SIMDs (the hyper modules at B*N rows): 4x shorter
+//             critical path.
 constexpr int kTypeSteps = 64;
 struct AggGroup {
   gn_agg_group_t a;
-  int split;  // 0 = whole, 1 = split
+  int wpr;
 };
+__device__ __forceinline__ void relu_scale16(f32x16& a, float w) {
+#if defined(GN_EXP_NO_VALU)
+  (void)w;
+#elif defined(GN_EXP_MED3)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = __builtin_amdgcn_fmed3f(a[r], 0.f, __builtin_inff()) * w;
+#else
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f) * w;
+#endif
+}
 __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
-  __shared__ float part[4][32][64];  // split mode only: [wave][register 0..31][lane]
+  __shared__ float part[4][32][64];  // wpr > 1 only: [wave][register 0..31][lane]
   const int gi = find_group(T, blockIdx.x);
   const gn_agg_group_t G = T.g[gi].a;
-  const bool split = T.g[gi].split != 0;
+  const int wpr = T.g[gi].wpr;
   const int rows = G.rows, K = G.K;
   const int wave = wave_id();
   const int wg = blockIdx.x - T.first_wg[gi];
-  const int blk = split ? wg : wg * 4 + wave;
-  if (!split && blk * 32 >= rows) return;
-  const RowBlock rb = row_block(rows, blk);
+  const int sub = wave % wpr;                       // which share of the types
+  const int blk = wg * (4 / wpr) + wave / wpr;      // which row block
+  const bool any_rows = blk * 32 < rows;
+  if (wpr == 1 && !any_rows) return;
+  const RowBlock rb = row_block(rows, any_rows ? blk : 0);
   const int lane = rb.lane, h = rb.h;
   f32x16 in[2], hid[4], out[2];
   load_rows<2>(G.eo, GN_FEAT, rb.row_ld, h, in);
@@ -325,10 +351,9 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
   const f32x4* Wl = reinterpret_cast<const f32x4*>(G.W) + lane;
   const float* b1 = G.b1;
   const float* b2 = G.b2;
-  const int kstride = split ? 4 : 1;
 
-  int k = split ? wave : 0;
-  if (k < K) {
+  int k = sub;
+  if (k < K && any_rows) {
     WRing ring;
     ring_prime(ring, Wl + (size_t)k * kTypeSteps * kStep);
     f32x16 bnext = load_bias_tile(b1 + k * 128, h);
@@ -338,26 +363,28 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
     float b2f1 = h == 0 ? b2[k * 64 + 32 + (lane & 31)] : 0.f;
 #pragma unroll 1
     while (k < K) {
-      const int kn = k + kstride;
+      const int kn = k + wpr;
       const int kc = kn < K ? kn : k;  // what the run-ahead loads target (valid memory either way)
       const f32x4* base = Wl + (size_t)k * kTypeSteps * kStep;
       const f32x4* base_next = Wl + (size_t)kc * kTypeSteps * kStep;
       const float efk_next = efrow[kc];
       const float b2n0 = h == 0 ? b2[kc * 64 + (lane & 31)] : 0.f;
       const float b2n1 = h == 0 ? b2[kc * 64 + 32 + (lane & 31)] : 0.f;
-      // layer 1: 4 tiles of 8 steps
+      // layer 1: 4 tiles of 8 steps; relu * ef_k of tile o-1 rides in the shadow of tile o's MFMAs
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
         hid[o] = bnext;
         bnext = load_bias_tile(o < 3 ? b1 + k * 128 + 32 * (o + 1) : b1 + kc * 128, h);
-        mma_tile<2>(base + o * 8 * kStep, base + (o + 1) * 8 * kStep, ring, in, hid[o]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hid[o][r] = fmaxf(hid[o][r], 0.f) * efk;
+        mma_tile<2>(base + o * 8 * kStep, base + (o + 1) * 8 * kStep, ring, in, hid[o], [&](int s) {
+          if (o > 0 && s == 1) relu_scale16(hid[o > 0 ? o - 1 : 0], efk);
+        });
       }
-      // layer 2: 2 tiles of 16 steps, accumulated over types
+      // layer 2: 2 tiles of 16 steps, accumulated over types (tile 0 touches hid[3] only from step 12 on)
       const float efb = h == 0 ? efk : 0.f;
       out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f0, efb, out[0], 0, 0, 0);
-      mma_tile<4>(base + 32 * kStep, base + 48 * kStep, ring, hid, out[0]);
+      mma_tile<4>(base + 32 * kStep, base + 48 * kStep, ring, hid, out[0], [&](int s) {
+        if (s == 1) relu_scale16(hid[3], efk);
+      });
       out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f1, efb, out[1], 0, 0, 0);
       mma_tile<4>(base + 48 * kStep, base_next, ring, hid, out[1]);
       efk = efk_next;
@@ -366,7 +393,7 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
       k = kn;
     }
   }
-  if (!split) {
+  if (wpr == 1) {
     store_rows<2>(G.feat, GN_FEAT, rb.row, h, rb.live, out);
     return;
   }
@@ -375,18 +402,21 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[wave][16 * o + r][lane] = out[o][r];
   __syncthreads();
-  // wave w finishes registers 8w .. 8w+7  (tile o = w >> 1, q = 2*(w&1) and 2*(w&1)+1)
-  if (rb.live) {
+  // the wpr waves of a row block each finish 32/wpr of its registers
+  if (rb.live && any_rows) {
     float* p = G.feat + (size_t)rb.row * GN_FEAT + 4 * h;
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-      f32x4 v;
-#pragma unroll
-      for (int cidx = 0; cidx < 4; ++cidx) {
-        const int reg = 8 * wave + 4 * qq + cidx;
-        v[cidx] = (part[0][reg][lane] + part[1][reg][lane]) + (part[2][reg][lane] + part[3][reg][lane]);
+    const int w0 = wave - sub;
+    const int nreg = 32 / wpr;
+    for (int rr = 0; rr < nreg; rr += 4) {
+      const int reg0 = sub * nreg + rr;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < wpr; ++j) {
+        v[0] += part[w0 + j][reg0 + 0][lane];
+        v[1] += part[w0 + j][reg0 + 1][lane];
+        v[2] += part[w0 + j][reg0 + 2][lane];
+        v[3] += part[w0 + j][reg0 + 3][lane];
       }
-      const int o = wave >> 1, q = 2 * (wave & 1) + qq;
+      const int o = reg0 >> 4, q = (reg0 & 15) >> 2;
       *reinterpret_cast<f32x4*>(p + 32 * o + 8 * q) = v;
     }
   }
@@ -532,12 +562,17 @@ extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_str
     GN_CHECK(need(G.b2, false));
     if (G.rows <= 0 || G.K < 1 || G.K > GN_MAX_TYPES) return GN_ERR_SHAPE;
     const int blocks32 = (G.rows + 31) / 32;
-    // a group with fewer row blocks than half the chip's 1024 SIMDs: split the types over 4 waves
-    const bool split = blocks32 <= 512 && G.K >= 4;
+    // waves per row block: 4 when the group has fewer row blocks than half the chip's 1024 SIMDs,
+    // else 2 when the types split evenly (shorter, more uniform work units), else 1
+    int wpr = (blocks32 <= 512 && G.K >= 4) ? 4 : ((G.K % 2 == 0 && G.K >= 4) ? 2 : 1);
+    if (const char* e = getenv("GN_AGG_WPR")) {  // tuning knob: force 1, 2 or 4
+      const int v = atoi(e);
+      if (v == 1 || v == 2 || v == 4) wpr = v;
+    }
     T.g[g].a = G;
-    T.g[g].split = split ? 1 : 0;
+    T.g[g].wpr = wpr;
     T.first_wg[g] = wg;
-    wg += split ? blocks32 : row_grid(G.rows);
+    wg += (blocks32 * wpr + 3) / 4;
   }
   T.first_wg[n_groups] = wg;
   hipLaunchKernelGGL(agg_mlp_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, T);
