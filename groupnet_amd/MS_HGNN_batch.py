@@ -322,7 +322,11 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
     if any(m.nmp_layers != nmp or m.bottleneck_dim != mods[0].bottleneck_dim for m in mods):
         raise ValueError("grouped modules must share nmp_layers and bottleneck_dim")
     B, N = hs[0].shape[0], hs[0].shape[1]
-    Es = [N * N if H is None else H.shape[1] for H in Hs]
+    Es = [N * N if H is None else H.shape[1] for H in Hs]   # ordered edges: the shape of noise and factors
+    # The pairwise graph is symmetric: edges (i,j) and (j,i) pool the same feature, meet the same typed
+    # MLP output and are summed into the same two nodes.  Its per-edge MLPs therefore run once per
+    # unordered pair (N(N+1)/2 rows instead of N*N); only the Gumbel softmax runs per ordered edge.
+    syms = [H is None for H in Hs]
     given = [_noise_iter(u) for u in noises]
 
     def next_u(i: int):
@@ -336,21 +340,22 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
     def node2edge(xs: Sequence[Tensor], idx: int) -> List[Tensor]:
         pks = [m._packed_n2e(idx) for m in mods]
         xpq = ops.node_mlp_grouped([(x, pk) for x, pk in zip(xs, pks)])
-        return ops.node2edge_grouped([(xp, pq, H, pk["w2"], pk["b2"]) for (xp, pq), H, pk in zip(xpq, Hs, pks)])
+        return ops.node2edge_grouped([(xp, pq, H, pk["w2"], pk["b2"], sy)
+                                      for (xp, pq), H, pk, sy in zip(xpq, Hs, pks, syms)])
 
-    def edge_mlp(stages, edges: Sequence[Tensor]):
+    def edge_mlp(stages, edges: Sequence[Tensor], want_dist: bool):
         # draws happen module by module, in the order given — the reference's RNG order per call site
         us = [next_u(i) for i in range(n)]
-        return ops.edge_mlp_gumbel_grouped([(e, u, st._packed(), st.bottleneck_dim)
-                                            for e, u, st in zip(edges, us, stages)], _GUMBEL_TAU)
+        return ops.edge_mlp_gumbel_grouped([(e, u, st._packed(), st.bottleneck_dim, N if sy else 0, want_dist)
+                                            for e, u, st, sy in zip(edges, us, stages, syms)], _GUMBEL_TAU)
 
     def edge2node(edge_feats: Sequence[Tensor], oris: Sequence[Tensor], idx: int) -> List[Tensor]:
         aggs = [m.edge_aggregation_list[idx] for m in mods]
-        eos = ops.agg_gather_grouped(list(zip(oris, Hs)))
+        eos = ops.agg_gather_grouped(list(zip(oris, Hs, syms)))
         feats = ops.agg_mlp_grouped([(eo, ef, a._packed(), a.edge_types) for eo, ef, a in zip(eos, edge_feats, aggs)])
-        return ops.agg_scatter_grouped([(f, H, o) for f, H, o in zip(feats, Hs, oris)])
+        return ops.agg_scatter_grouped([(f, H, o, sy) for f, H, o, sy in zip(feats, Hs, oris, syms)])
 
-    res = edge_mlp([m.nmp_mlp_start for m in mods], node2edge(hs, 0))
+    res = edge_mlp([m.nmp_mlp_start for m in mods], node2edge(hs, 0), True)
     edge_feats, factors = [r[0] for r in res], [r[1] for r in res]
     node_feats, idx = list(hs), 0
     for l in range(2 * (nmp - 1)):
@@ -360,7 +365,7 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
             node_feats = ops.mlp2_grouped([(a, m._packed_mlp2(st), None) for a, m, st in zip(agg, mods, stages)])
             idx += 1
         else:
-            edge_feats = [r[0] for r in edge_mlp(stages, node2edge(node_feats, idx))]
+            edge_feats = [r[0] for r in edge_mlp(stages, node2edge(node_feats, idx), False)]
     agg = edge2node(edge_feats, node_feats, idx)
     ends = [(a, m._packed_mlp2(m.nmp_mlp_end), o) for a, m, o in zip(agg, mods, outs)]
     # the last MLP writes in place when `out` is given; grouped when every group has the same stride

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -30,16 +30,16 @@ class NodeGroup(ctypes.Structure):      # gn_node_group_t
 
 
 class N2EGroup(ctypes.Structure):       # gn_n2e_group_t
-    _fields_ = [("xp", _P), ("pq", _P), ("H", _P), ("w2", _P), ("edges", _P), ("b2", _F), ("E", _I)]
+    _fields_ = [("xp", _P), ("pq", _P), ("H", _P), ("w2", _P), ("edges", _P), ("b2", _F), ("E", _I), ("sym", _I)]
 
 
 class EdgeGroup(ctypes.Structure):      # gn_edge_group_t
     _fields_ = [("edges", _P), ("U", _P), ("W", _P), ("bias", _P), ("edge_feat", _P), ("dist", _P),
-                ("philox_offset", _U64), ("rows", _I), ("K", _I)]
+                ("philox_offset", _U64), ("rows", _I), ("K", _I), ("sym_N", _I)]
 
 
 class GatherGroup(ctypes.Structure):    # gn_gather_group_t
-    _fields_ = [("ori", _P), ("H", _P), ("eo", _P), ("E", _I)]
+    _fields_ = [("ori", _P), ("H", _P), ("eo", _P), ("E", _I), ("sym", _I)]
 
 
 class AggGroup(ctypes.Structure):       # gn_agg_group_t
@@ -48,7 +48,7 @@ class AggGroup(ctypes.Structure):       # gn_agg_group_t
 
 
 class ScatterGroup(ctypes.Structure):   # gn_scatter_group_t
-    _fields_ = [("feat", _P), ("H", _P), ("ori", _P), ("out", _P), ("E", _I)]
+    _fields_ = [("feat", _P), ("H", _P), ("ori", _P), ("out", _P), ("E", _I), ("sym", _I)]
 
 
 class Mlp2Group(ctypes.Structure):      # gn_mlp2_group_t

@@ -89,3 +89,20 @@ __device__ __forceinline__ float gn_philox_uniform_at(unsigned long long idx, un
   const uint32_t x = l == 0 ? c[0] : (l == 1 ? c[1] : (l == 2 ? c[2] : c[3]));
   return gn_philox_to_uniform(x);
 }
+
+// Unordered pairs (i <= j) of N nodes, row-major over i: p(i,j) = i*N - i(i-1)/2 + (j - i).
+__host__ __device__ __forceinline__ int gn_pair_count(int N) { return N * (N + 1) / 2; }
+__device__ __forceinline__ int gn_pair_start(int i, int N) { return i * N - (i * (i - 1)) / 2; }
+__device__ __forceinline__ int gn_pair_index(int a, int b, int N) {  // any order
+  const int i = a < b ? a : b, j = a < b ? b : a;
+  return gn_pair_start(i, N) + (j - i);
+}
+__device__ __forceinline__ void gn_pair_decode(int p, int N, int& i, int& j) {
+  const float t = (float)(2 * N + 1);
+  int r = (int)((t - sqrtf(t * t - 8.f * (float)p)) * 0.5f);
+  r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
+  while (r + 1 < N && gn_pair_start(r + 1, N) <= p) ++r;
+  while (r > 0 && gn_pair_start(r, N) > p) --r;
+  i = r;
+  j = r + (p - gn_pair_start(r, N));
+}

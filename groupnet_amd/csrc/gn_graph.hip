@@ -260,7 +260,8 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
                                                                    int bands) {
   extern __shared__ __align__(16) float lds[];
   constexpr int LDP = GN_FEAT + 1;
-  const int E = N * N;
+  const bool sym = G.sym != 0;
+  const int E = sym ? gn_pair_count(N) : N * N;   // edge rows per scene
   const int b0 = (blockIdx.x / bands) * SG;
   const int band = blockIdx.x % bands;
   const int sg = min(SG, B - b0);
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
   float* s_pq = s_xp + (size_t)SG * N * GN_FEAT;    // sg x N x 65
   float* s_w = s_pq + (size_t)SG * N * LDP;         // 256 x 2 edge weights of the current band
   float* s_w2 = s_w + 2 * kBlock;                   // 32
+  int* s_ij = reinterpret_cast<int*>(s_w2 + 32);    // 256 packed (i, j) of the current band
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(G.xp + (size_t)b0 * N * GN_FEAT);
     f32x4* dst = reinterpret_cast<f32x4*>(s_xp);
@@ -287,7 +289,14 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
     const long long eidx = base + threadIdx.x;
     if (eidx < hi) {
       const int s = (int)(eidx / E), e = (int)(eidx - (long long)s * E);
-      const int i = e / N, j = e - i * N;
+      int i, j;
+      if (sym) {
+        gn_pair_decode(e, N, i, j);
+      } else {
+        i = e / N;
+        j = e - i * N;
+      }
+      s_ij[threadIdx.x] = i | (j << 16);
       const float* pi = s_pq + (size_t)(s * N + i) * LDP;
       const float* pj = s_pq + (size_t)(s * N + j) * LDP;
       float ai = 0.f, aj = 0.f;
@@ -324,8 +333,9 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
     for (int idx = threadIdx.x; idx < nb * 16; idx += kBlock) {
       const int t = idx >> 4, d = idx & 15;
       const long long eidx = base + t;
-      const int s = (int)(eidx / E), e = (int)(eidx - (long long)s * E);
-      const int i = e / N, j = e - i * N;
+      const int s = (int)(eidx / E);
+      const int ij = s_ij[t];
+      const int i = ij & 0xffff, j = ij >> 16;
       const float wi = s_w[2 * t], wj = s_w[2 * t + 1];
       const f32x4 xi = reinterpret_cast<const f32x4*>(s_xp + (size_t)(s * N + i) * GN_FEAT)[d];
       const f32x4 xj = reinterpret_cast<const f32x4*>(s_xp + (size_t)(s * N + j) * GN_FEAT)[d];
@@ -384,16 +394,23 @@ __global__ __launch_bounds__(kBlock) void agg_gather_kernel(GatherTable T, int B
 }
 
 // Pairwise graph: eo[(i,j)] = ori_i + ori_j (2 ori_i on the diagonal), H never materialised.
+template <bool SYM>
 __global__ __launch_bounds__(kBlock) void agg_gather_pairwise_kernel(const float* __restrict__ ori,
                                                                      float* __restrict__ eo, int N,
                                                                      long long total4) {
-  const int E = N * N;
+  const int E = SYM ? gn_pair_count(N) : N * N;
   for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total4;
        idx += (long long)gridDim.x * kBlock) {
     const int d = (int)(idx & 15);
     const long long be = idx >> 4;
     const int b = (int)(be / E), e = (int)(be - (long long)b * E);
-    const int i = e / N, j = e - i * N;
+    int i, j;
+    if (SYM) {
+      gn_pair_decode(e, N, i, j);
+    } else {
+      i = e / N;
+      j = e - i * N;
+    }
     const f32x4* o4 = reinterpret_cast<const f32x4*>(ori + (size_t)b * N * GN_FEAT) + d;
     const f32x4 a = o4[i * 16], c = o4[j * 16];
     f32x4 r = {a[0] + c[0], a[1] + c[1], a[2] + c[2], a[3] + c[3]};
@@ -448,7 +465,8 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_kernel(ScatterTable T, int
 
 // Large-E / pairwise scatter straight from global memory (feat rows are 256-byte lines; every
 // row is read by exactly two nodes in the pairwise case, so the second read is an L2 hit).
-template <bool PAIRWISE>
+// MODE 0: general H (large E); 1: pairwise, E = N*N ordered edges; 2: pairwise, E = N(N+1)/2 pair sums
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const float* __restrict__ feat,
                                                                     const float* __restrict__ H,
                                                                     const float* __restrict__ ori,
@@ -463,7 +481,16 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const float*
     if (d < 16) {
       acc = {0.f, 0.f, 0.f, 0.f};
       const f32x4* f4 = reinterpret_cast<const f32x4*>(feat + (size_t)b * E * GN_FEAT) + d;
-      if (PAIRWISE) {
+      if (MODE == 2) {
+        // every pair {n,j} once: the pair row already holds both ordered edges (and the self-loop's 2)
+        for (int j = 0; j < N; ++j) {
+          const f32x4 v = f4[(size_t)gn_pair_index(n, j, N) * 16];
+          acc[0] += v[0];
+          acc[1] += v[1];
+          acc[2] += v[2];
+          acc[3] += v[3];
+        }
+      } else if (MODE == 1) {
         // (n,n) counts twice (H = 2 on self-loops); fp32 tolerance makes the edge order immaterial
         for (int j = 0; j < N; ++j) {
           const f32x4 v = f4[(size_t)(n * N + j) * 16];
@@ -536,7 +563,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) 
 
 }  // namespace
 
-extern "C" int gn_abi_version(void) { return 4; }
+extern "C" int gn_abi_version(void) { return 5; }
 
 extern "C" const char* gn_strerror(int code) {
   switch (code) {
@@ -622,9 +649,10 @@ extern "C" int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int 
     if (G.E <= 0) return GN_ERR_SHAPE;
     if (!gn_aligned16(G.xp) || !gn_aligned16(G.edges)) return GN_ERR_ALIGN;
     if (G.H == nullptr) {
-      if ((long long)G.E != (long long)N * N) return GN_ERR_SHAPE;
+      if ((long long)G.E != (G.sym ? (long long)gn_pair_count(N) : (long long)N * N)) return GN_ERR_SHAPE;
       continue;
     }
+    if (G.sym) return GN_ERR_SHAPE;  // the symmetric form exists for the pairwise graph only
     T.g[T.n] = G;
     T.first[T.n] = waves;
     waves += (long long)B * G.E;
@@ -638,11 +666,11 @@ extern "C" int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int 
     const gn_n2e_group_t& G = groups[g];
     if (G.H != nullptr) continue;
     const size_t per_scene = (size_t)N * (GN_FEAT + GN_FEAT + 1) * sizeof(float);
-    const size_t fixed = (2 * kBlock + 32) * sizeof(float);
-    if (per_scene + fixed > kLdsBudget) return GN_ERR_LDS;
+    const size_t fixed = (3 * kBlock + 32) * sizeof(float);
+    if (per_scene + fixed > kLdsBudget || N > 32767) return GN_ERR_LDS;
     int SG = 1;
     while (SG < 8 && (size_t)(2 * SG) * per_scene <= 32 * 1024 && (B + 2 * SG - 1) / (2 * SG) >= 512) SG *= 2;
-    const long long edges_per_wg = (long long)SG * N * N;
+    const long long edges_per_wg = (long long)SG * G.E;
     int bands = 1;
     while (bands < 64 && edges_per_wg / (bands * 2) >= 2048 && (long long)((B + SG - 1) / SG) * bands < 2048)
       bands *= 2;
@@ -675,8 +703,9 @@ extern "C" int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, 
     if (!gn_aligned16(G.ori) || !gn_aligned16(G.eo)) return GN_ERR_ALIGN;
     if (G.E <= 0) return GN_ERR_SHAPE;
     if (G.H == nullptr) {
-      if ((long long)G.E != (long long)N * N) return GN_ERR_SHAPE;
+      if ((long long)G.E != (G.sym ? (long long)gn_pair_count(N) : (long long)N * N)) return GN_ERR_SHAPE;
     } else {
+      if (G.sym) return GN_ERR_SHAPE;
       T.g[nh++] = G;
       Emax = G.E > Emax ? G.E : Emax;
     }
@@ -685,8 +714,11 @@ extern "C" int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, 
     const gn_gather_group_t& G = groups[g];
     if (G.H != nullptr) continue;
     const long long total4 = (long long)B * G.E * 16;
-    hipLaunchKernelGGL(agg_gather_pairwise_kernel, dim3(capped_grid(total4, kBlock * 4)), dim3(kBlock), 0, s, G.ori,
-                       G.eo, N, total4);
+    const dim3 grid(capped_grid(total4, kBlock * 4));
+    if (G.sym)
+      hipLaunchKernelGGL((agg_gather_pairwise_kernel<true>), grid, dim3(kBlock), 0, s, G.ori, G.eo, N, total4);
+    else
+      hipLaunchKernelGGL((agg_gather_pairwise_kernel<false>), grid, dim3(kBlock), 0, s, G.ori, G.eo, N, total4);
   }
   if (nh > 0) {
     const size_t ori_b = (size_t)N * GN_FEAT * sizeof(float);
@@ -723,15 +755,20 @@ extern "C" int gn_agg_scatter_f32(const gn_scatter_group_t* groups, int n_groups
     if (!G.feat || !G.ori || !G.out) return GN_ERR_NULL;
     if (!gn_aligned16(G.feat) || !gn_aligned16(G.ori) || !gn_aligned16(G.out)) return GN_ERR_ALIGN;
     if (G.E <= 0) return GN_ERR_SHAPE;
-    if (G.H == nullptr && (long long)G.E != (long long)N * N) return GN_ERR_SHAPE;
+    if (G.H == nullptr && (long long)G.E != (G.sym ? (long long)gn_pair_count(N) : (long long)N * N))
+      return GN_ERR_SHAPE;
+    if (G.H != nullptr && G.sym) return GN_ERR_SHAPE;
   }
   for (int g = 0; g < n_groups; ++g) {
     const gn_scatter_group_t& G = groups[g];
-    if (G.H == nullptr) {
-      hipLaunchKernelGGL((agg_scatter_direct_kernel<true>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
+    if (G.H == nullptr && G.sym) {
+      hipLaunchKernelGGL((agg_scatter_direct_kernel<2>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
+                         G.feat, G.H, G.ori, G.out, N, G.E, total4, divisor);
+    } else if (G.H == nullptr) {
+      hipLaunchKernelGGL((agg_scatter_direct_kernel<1>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
                          G.feat, G.H, G.ori, G.out, N, G.E, total4, divisor);
     } else if ((size_t)G.E * (GN_FEAT + N) * sizeof(float) > kLdsBudget / 2) {
-      hipLaunchKernelGGL((agg_scatter_direct_kernel<false>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
+      hipLaunchKernelGGL((agg_scatter_direct_kernel<0>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
                          G.feat, G.H, G.ori, G.out, N, G.E, total4, divisor);
     } else {
       T.g[nh++] = G;

@@ -225,6 +225,47 @@ __global__ __launch_bounds__(256) void node_mlp_kernel(GroupTable<gn_node_group_
 
 // ---- A4: z = MLP(64->128->64); [dist|fac] heads; gumbel softmax; sigmoid ------------------------
 // W = [Wi0 (128x64) | Wi1 (64x128) | Wd0 (256x64) | Wd1 (32x256)] packed, bias likewise.
+
+// Gumbel softmax over the K logits of a row whose features are split over its two lanes (j, h=0/1):
+// d[r] = softmax_f((lg_f + g_f) / tau), g = -log(eps - log(u + eps))   (MS_HGNN_batch.py:446-473).
+__device__ __forceinline__ void gumbel_softmax_row(const f32x16& lg, const float (&u)[8], int K, float tau, int h,
+                                                   float (&d)[8]) {
+  const float eps = 1e-10f;  // MS_HGNN_batch.py:446
+  float y[8];
+  float m = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float g = -logf(eps - logf(u[r] + eps));
+    y[r] = (lg[r] + g) / tau;
+    if (feat_of(r, h) < K) m = fmaxf(m, y[r]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, GN_WAVE));
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    d[r] = (feat_of(r, h) < K) ? expf(y[r] - m) : 0.f;
+    s += d[r];
+  }
+  s += __shfl_xor(s, 32, GN_WAVE);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) d[r] = d[r] / s;
+}
+
+// uniforms of this lane's features for ordered row `orow`: from U, or from the Philox stream
+__device__ __forceinline__ void fetch_uniforms(const float* __restrict__ U, unsigned long long base,
+                                               unsigned long long seed, long long orow, int K, int h, float (&u)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int f = feat_of(r, h);
+    if (f >= K)
+      u[r] = 0.5f;
+    else if (U != nullptr)
+      u[r] = U[(size_t)orow * K + f];
+    else
+      u[r] = gn_philox_uniform_at(base + (unsigned long long)orow * K + f, seed);
+  }
+}
+
 __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge_group_t> T, float tau,
                                                               unsigned long long seed,
                                                               const unsigned long long* __restrict__ offset_dev) {
@@ -238,65 +279,71 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge
   chain_begin(c, G.W, G.bias, rb.lane);
   f32x16 in[2], h1[4], z[2], h2[8], lg[1];
   load_rows<2>(G.edges, GN_FEAT, rb.row_ld, rb.h, in);
-  // The uniforms of this lane's features: read from U (issued now, far ahead of the epilogue) or, with
-  // U == NULL, element row*K + f of the Philox stream at `philox_offset` (+ the device counter) — computed
-  // on the VALU after the MFMAs are queued, so it costs no HBM traffic and no extra launch.
-  float u[8];
+  // Ordered edge rows whose uniforms this row consumes: itself, or — symmetric pairwise form — the two
+  // ordered edges (i,j) and (j,i) of its unordered pair.
+  long long o1 = rb.row_ld, o2 = rb.row_ld;
+  bool diag = true;
+  if (G.sym_N > 0) {
+    const int N = G.sym_N, P = gn_pair_count(N);
+    const int b = rb.row_ld / P, p = rb.row_ld - b * P;
+    int i, j;
+    gn_pair_decode(p, N, i, j);
+    o1 = (long long)b * N * N + i * N + j;
+    o2 = (long long)b * N * N + j * N + i;
+    diag = i == j;
+  }
+  // With a U tensor the loads are issued now, far ahead of the epilogue; Philox values are computed on
+  // the VALU after the MFMAs are queued (no HBM traffic, no extra launch).
+  float u1[8], u2[8];
+  const unsigned long long pbase = G.philox_offset + (offset_dev ? *offset_dev : 0ull);
   if (G.U != nullptr) {
-    const float* urow = G.U + (size_t)rb.row_ld * K;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int f = feat_of(r, rb.h);
-      u[r] = f < K ? urow[f] : 0.5f;
-    }
+    fetch_uniforms(G.U, 0ull, 0ull, o1, K, rb.h, u1);
+    if (G.sym_N > 0) fetch_uniforms(G.U, 0ull, 0ull, o2, K, rb.h, u2);
   }
   chain_linear<4, 2, true>(c, in, h1);
   chain_linear<2, 4, false>(c, h1, z);
   chain_linear<8, 2, true>(c, z, h2);
   chain_linear<1, 8, false>(c, h2, lg, true);
-
   if (G.U == nullptr) {
-    const unsigned long long base =
-        G.philox_offset + (offset_dev ? *offset_dev : 0ull) + (unsigned long long)rb.row_ld * K;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int f = feat_of(r, rb.h);
-      u[r] = f < K ? gn_philox_uniform_at(base + f, seed) : 0.5f;
-    }
+    fetch_uniforms(nullptr, pbase, seed, o1, K, rb.h, u1);
+    if (G.sym_N > 0) fetch_uniforms(nullptr, pbase, seed, o2, K, rb.h, u2);
   }
+
   // Epilogue.  Features 0..K-1 of `lg` are the logits of this lane's row, feature K the factor
   // pre-activation; a row's features are split over its two lanes (j, h=0) and (j, h=1).
-  const float eps = 1e-10f;  // MS_HGNN_batch.py:446
-  float y[8], e[8];
-  float m = -INFINITY, facv = 0.f;
+  float facv = 0.f;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int f = feat_of(r, rb.h);
-    const float g = -logf(eps - logf(u[r] + eps));
-    y[r] = (lg[0][r] + g) / tau;
-    if (f < K) m = fmaxf(m, y[r]);
-    if (f == K) facv = lg[0][r];
-  }
-  m = fmaxf(m, __shfl_xor(m, 32, GN_WAVE));
-  float s = 0.f;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    e[r] = (feat_of(r, rb.h) < K) ? expf(y[r] - m) : 0.f;
-    s += e[r];
-  }
-  s += __shfl_xor(s, 32, GN_WAVE);
+  for (int r = 0; r < 8; ++r)
+    if (feat_of(r, rb.h) == K) facv = lg[0][r];
   facv += __shfl_xor(facv, 32, GN_WAVE);  // exactly one of the two lanes holds it, the other has 0
   const float sig = 1.f / (1.f + expf(-facv));
+  float d1[8], d2[8];
+  gumbel_softmax_row(lg[0], u1, K, tau, rb.h, d1);
+  if (G.sym_N > 0) gumbel_softmax_row(lg[0], u2, K, tau, rb.h, d2);
   if (rb.live) {
-    float* drow = G.dist + (size_t)rb.row * K;
     float* frow = G.edge_feat + (size_t)rb.row * K;
+    if (G.sym_N == 0) {
+      float* drow = G.dist + (size_t)rb.row * K;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int f = feat_of(r, rb.h);
-      if (f < K) {
-        const float d = e[r] / s;
-        drow[f] = d;
-        frow[f] = sig * d;
+      for (int r = 0; r < 8; ++r) {
+        const int f = feat_of(r, rb.h);
+        if (f < K) {
+          drow[f] = d1[r];
+          frow[f] = sig * d1[r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int f = feat_of(r, rb.h);
+        if (f < K) {
+          if (G.dist != nullptr) {
+            G.dist[(size_t)o1 * K + f] = d1[r];
+            if (!diag) G.dist[(size_t)o2 * K + f] = d2[r];
+          }
+          // both ordered edges meet the same typed MLP output downstream; the self-loop has weight 2
+          frow[f] = diag ? 2.f * (sig * d1[r]) : sig * d1[r] + sig * d2[r];
+        }
       }
     }
   }
@@ -536,8 +583,9 @@ extern "C" int gn_edge_mlp_gumbel_f32(const gn_edge_group_t* groups, int n_group
     GN_CHECK(need(G.W, true));
     GN_CHECK(need(G.bias, true));
     GN_CHECK(need(G.edge_feat, false));
-    GN_CHECK(need(G.dist, false));
-    if (G.rows <= 0 || G.K < 1 || G.K > 15) return GN_ERR_SHAPE;
+    if (G.sym_N == 0) GN_CHECK(need(G.dist, false));
+    if (G.rows <= 0 || G.K < 1 || G.K > 15 || G.sym_N < 0) return GN_ERR_SHAPE;
+    if (G.sym_N > 0 && G.rows % gn_pair_count(G.sym_N) != 0) return GN_ERR_SHAPE;
     T.g[g] = G;
     T.first_wg[g] = wg;
     wg += row_grid(G.rows);

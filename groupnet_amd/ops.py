@@ -163,35 +163,45 @@ def node_mlp(x: Tensor, pk: dict) -> Tuple[Tensor, Tensor]:
     return node_mlp_grouped([(x, pk)])[0]
 
 
-def node2edge_grouped(items: Sequence[Tuple[Tensor, Tensor, Optional[Tensor], Tensor, float]]) -> List[Tensor]:
-    """items = [(xp, pq, H or None, w2, b2)] over the same (B, N); returns [edges (B,E,64)].
-    H=None selects the implicit pairwise graph (E = N*N)."""
+def pair_count(N: int) -> int:
+    """Unordered pairs (i <= j) of N nodes — rows per scene of the symmetric pairwise form."""
+    return N * (N + 1) // 2
+
+
+def node2edge_grouped(items: Sequence[tuple]) -> List[Tensor]:
+    """items = [(xp, pq, H or None, w2, b2[, sym])] over the same (B, N); returns [edges (B,E,64)].
+    H=None selects the implicit pairwise graph: E = N*N ordered edges, or with sym=True the
+    N(N+1)/2 unordered pairs (edges (i,j) and (j,i) carry the same feature)."""
     _groups(len(items))
     xp0 = _req(items[0][0], "xp", (None, None, FEAT))
     B, N, _ = xp0.shape
     arr = (_lib.N2EGroup * len(items))()
     outs = []
-    for g, (xp, pq, H, w2, b2) in enumerate(items):
+    for g, item in enumerate(items):
+        xp, pq, H, w2, b2 = item[:5]
+        sym = bool(item[5]) if len(item) > 5 else False
         _req(xp, "xp", (B, N, FEAT))
         _req(pq, "pq", (B, N, FEAT))
         if H is None:
-            E = N * N
+            E = pair_count(N) if sym else N * N
         else:
+            if sym:
+                raise ValueError("sym applies to the pairwise graph (H=None) only")
             _req(H, "H", (B, None, N))
             E = H.shape[1]
         _req(w2, "w2", (32,))
         _same_device(xp0, xp, pq, H, w2)
         edges = torch.empty((B, E, FEAT), dtype=xp.dtype, device=xp.device)
         arr[g] = _lib.N2EGroup(xp.data_ptr(), pq.data_ptr(), 0 if H is None else H.data_ptr(), w2.data_ptr(),
-                               edges.data_ptr(), float(b2), E)
+                               edges.data_ptr(), float(b2), E, int(sym))
         outs.append(edges)
     with torch.cuda.device(xp0.device):
         check(load().gn_node2edge_f32(arr, len(items), B, N, stream_handle()), "gn_node2edge_f32")
     return outs
 
 
-def node2edge(xp: Tensor, pq: Tensor, H: Optional[Tensor], w2: Tensor, b2: float) -> Tensor:
-    return node2edge_grouped([(xp, pq, H, w2, b2)])[0]
+def node2edge(xp: Tensor, pq: Tensor, H: Optional[Tensor], w2: Tensor, b2: float, sym: bool = False) -> Tensor:
+    return node2edge_grouped([(xp, pq, H, w2, b2, sym)])[0]
 
 
 # ---- A4 ------------------------------------------------------------------------------------------
@@ -206,19 +216,28 @@ class PhiloxNoise:
         self.seed, self.offset, self.counter = int(seed) & (2**64 - 1), int(offset), counter
 
 
-def edge_mlp_gumbel_grouped(items: Sequence[Tuple[Tensor, object, dict, int]], tau: float = 0.5
-                            ) -> List[Tuple[Tensor, Tensor]]:
-    """items = [(edges (B,E,64), U tensor (B,E,K) or PhiloxNoise, pk, K)]; returns [(edge_feat, dist)].
-    All PhiloxNoise entries of one call must share seed and counter (one stream per launch)."""
+def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5) -> List[Tuple[Tensor, Optional[Tensor]]]:
+    """items = [(edges (B,E,64), U tensor (B,E,K) or PhiloxNoise, pk, K[, sym_N[, want_dist]])];
+    returns [(edge_feat, dist)].  All PhiloxNoise entries of one call must share seed and counter.
+
+    sym_N = N > 0: `edges` holds the (B, N(N+1)/2, 64) unordered-pair rows of the pairwise graph; U /
+    the Philox positions and `dist` are those of the ORDERED (B, N*N, K) tensor; edge_feat is
+    (B, N(N+1)/2, K) = fac * (dist_ij + dist_ji).  want_dist=False skips the ordered dist output."""
     _groups(len(items))
     e0 = items[0][0]
     arr = (_lib.EdgeGroup * len(items))()
     outs = []
     seed, ctr = None, None
-    for g, (edges, U, pk, K) in enumerate(items):
+    for g, item in enumerate(items):
+        edges, U, pk, K = item[:4]
+        sym_N = int(item[4]) if len(item) > 4 else 0
+        want_dist = bool(item[5]) if len(item) > 5 else True
         _req(edges, "edges", (None, None, FEAT))
         _same_device(e0, edges)
         B, E, _ = edges.shape
+        if sym_N and E != pair_count(sym_N):
+            raise ValueError(f"edges: symmetric form needs {pair_count(sym_N)} pair rows per scene, got {E}")
+        Eo = sym_N * sym_N if sym_N else E          # ordered edges per scene (noise / dist layout)
         if isinstance(U, PhiloxNoise):
             if seed is None:
                 seed, ctr = U.seed, U.counter
@@ -226,13 +245,13 @@ def edge_mlp_gumbel_grouped(items: Sequence[Tuple[Tensor, object, dict, int]], t
                 raise ValueError("all PhiloxNoise groups of one launch must share seed and counter")
             u_ptr, off = 0, U.offset
         else:
-            _req(U, "noise_u", (B, E, K))
+            _req(U, "noise_u", (B, Eo, K))
             _same_device(edges, U)
             u_ptr, off = U.data_ptr(), 0
         edge_feat = torch.empty((B, E, K), dtype=edges.dtype, device=edges.device)
-        dist = torch.empty_like(edge_feat)
+        dist = torch.empty((B, Eo, K), dtype=edges.dtype, device=edges.device) if (want_dist or not sym_N) else None
         arr[g] = _lib.EdgeGroup(edges.data_ptr(), u_ptr, pk["W"].data_ptr(), pk["bias"].data_ptr(),
-                                edge_feat.data_ptr(), dist.data_ptr(), off, B * E, K)
+                                edge_feat.data_ptr(), 0 if dist is None else dist.data_ptr(), off, B * E, K, sym_N)
         outs.append((edge_feat, dist))
     with torch.cuda.device(e0.device):
         check(load().gn_edge_mlp_gumbel_f32(arr, len(items), float(tau), seed or 0, _ptr(ctr), stream_handle()),
@@ -246,34 +265,38 @@ def edge_mlp_gumbel(edges: Tensor, U, pk: dict, K: int, tau: float = 0.5) -> Tup
 
 
 # ---- A5 ------------------------------------------------------------------------------------------
-def _edge_count(H: Optional[Tensor], B: int, N: int) -> int:
+def _edge_count(H: Optional[Tensor], B: int, N: int, sym: bool = False) -> int:
     if H is None:
-        return N * N
+        return pair_count(N) if sym else N * N
+    if sym:
+        raise ValueError("sym applies to the pairwise graph (H=None) only")
     _req(H, "H", (B, None, N))
     return H.shape[1]
 
 
-def agg_gather_grouped(items: Sequence[Tuple[Tensor, Optional[Tensor]]]) -> List[Tensor]:
-    """items = [(ori (B,N,64), H (B,E,N) or None)] -> [eo (B,E,64)]."""
+def agg_gather_grouped(items: Sequence[tuple]) -> List[Tensor]:
+    """items = [(ori (B,N,64), H (B,E,N) or None[, sym])] -> [eo (B,E,64)]."""
     _groups(len(items))
     o0 = _req(items[0][0], "ori", (None, None, FEAT))
     B, N, _ = o0.shape
     arr = (_lib.GatherGroup * len(items))()
     outs = []
-    for g, (ori, H) in enumerate(items):
+    for g, item in enumerate(items):
+        ori, H = item[:2]
+        sym = bool(item[2]) if len(item) > 2 else False
         _req(ori, "ori", (B, N, FEAT))
-        E = _edge_count(H, B, N)
+        E = _edge_count(H, B, N, sym)
         _same_device(o0, ori, H)
         eo = torch.empty((B, E, FEAT), dtype=ori.dtype, device=ori.device)
-        arr[g] = _lib.GatherGroup(ori.data_ptr(), 0 if H is None else H.data_ptr(), eo.data_ptr(), E)
+        arr[g] = _lib.GatherGroup(ori.data_ptr(), 0 if H is None else H.data_ptr(), eo.data_ptr(), E, int(sym))
         outs.append(eo)
     with torch.cuda.device(o0.device):
         check(load().gn_agg_gather_f32(arr, len(items), B, N, stream_handle()), "gn_agg_gather_f32")
     return outs
 
 
-def agg_gather(ori: Tensor, H: Optional[Tensor]) -> Tensor:
-    return agg_gather_grouped([(ori, H)])[0]
+def agg_gather(ori: Tensor, H: Optional[Tensor], sym: bool = False) -> Tensor:
+    return agg_gather_grouped([(ori, H, sym)])[0]
 
 
 def agg_mlp_grouped(items: Sequence[Tuple[Tensor, Tensor, dict, int]]) -> List[Tensor]:
@@ -307,22 +330,24 @@ def agg_mlp(eo: Tensor, edge_feat: Tensor, pk: dict, K: int) -> Tensor:
     return agg_mlp_grouped([(eo, edge_feat, pk, K)])[0]
 
 
-def agg_scatter_grouped(items: Sequence[Tuple[Tensor, Optional[Tensor], Tensor]], divisor: Optional[float] = None
-                        ) -> List[Tensor]:
-    """items = [(feat (B,E,64), H or None, ori (B,N,64))] -> [cat(H^T feat, ori) / divisor (B,N,128)];
-    divisor defaults to N (edge2node, model/MS_HGNN_batch.py:120,355)."""
+def agg_scatter_grouped(items: Sequence[tuple], divisor: Optional[float] = None) -> List[Tensor]:
+    """items = [(feat (B,E,64), H or None, ori (B,N,64)[, sym])] -> [cat(H^T feat, ori) / divisor
+    (B,N,128)]; divisor defaults to N (edge2node, model/MS_HGNN_batch.py:120,355)."""
     _groups(len(items))
     o0 = _req(items[0][2], "ori", (None, None, FEAT))
     B, N, _ = o0.shape
     arr = (_lib.ScatterGroup * len(items))()
     outs = []
-    for g, (feat, H, ori) in enumerate(items):
+    for g, item in enumerate(items):
+        feat, H, ori = item[:3]
+        sym = bool(item[3]) if len(item) > 3 else False
         _req(ori, "ori", (B, N, FEAT))
-        E = _edge_count(H, B, N)
+        E = _edge_count(H, B, N, sym)
         _req(feat, "feat", (B, E, FEAT))
         _same_device(o0, feat, ori, H)
         out = torch.empty((B, N, 2 * FEAT), dtype=ori.dtype, device=ori.device)
-        arr[g] = _lib.ScatterGroup(feat.data_ptr(), 0 if H is None else H.data_ptr(), ori.data_ptr(), out.data_ptr(), E)
+        arr[g] = _lib.ScatterGroup(feat.data_ptr(), 0 if H is None else H.data_ptr(), ori.data_ptr(), out.data_ptr(), E,
+                                   int(sym))
         outs.append(out)
     with torch.cuda.device(o0.device):
         check(load().gn_agg_scatter_f32(arr, len(items), B, N, float(N if divisor is None else divisor),
@@ -330,8 +355,9 @@ def agg_scatter_grouped(items: Sequence[Tuple[Tensor, Optional[Tensor], Tensor]]
     return outs
 
 
-def agg_scatter(feat: Tensor, H: Optional[Tensor], ori: Tensor, divisor: Optional[float] = None) -> Tensor:
-    return agg_scatter_grouped([(feat, H, ori)], divisor)[0]
+def agg_scatter(feat: Tensor, H: Optional[Tensor], ori: Tensor, divisor: Optional[float] = None,
+                sym: bool = False) -> Tensor:
+    return agg_scatter_grouped([(feat, H, ori, sym)], divisor)[0]
 
 
 # ---- A6 ------------------------------------------------------------------------------------------

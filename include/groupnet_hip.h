@@ -109,7 +109,10 @@ int gn_node_mlp_f32(const gn_node_group_t* groups, int n_groups, int rows, gn_st
  *   Qn = pq[:, 32:];  W = softmax_n(att * H) * H;  edges = W x'.
  * H == NULL selects the pairwise graph of MS_HGNN_oridinary (E must be N*N; edge e = i*N + j has
  * weight 1 on i and on j, 2 when i == j; MS_HGNN_batch.py:118,124,143-160) without ever
- * materialising it.  xp, pq (B,N,64); H (B,E,N) or NULL; w2 (32 floats, device); edges (B,E,64). */
+ * materialising it.  xp, pq (B,N,64); H (B,E,N) or NULL; w2 (32 floats, device); edges (B,E,64).
+ * Symmetric pairwise form (H == NULL, sym = 1): edge (i,j) and edge (j,i) of the pairwise graph carry
+ * the same pooled feature, so only the N(N+1)/2 unordered pairs are produced: E = N(N+1)/2, row
+ * p(i,j) = i*N - i(i-1)/2 + (j-i) for i <= j.  Every pairwise stage below has the matching form. */
 typedef struct {
   const float* xp;
   const float* pq;
@@ -118,6 +121,7 @@ typedef struct {
   float* edges;
   float b2;
   int E;
+  int sym;
 } gn_n2e_group_t;
 int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, gn_stream_t stream);
 
@@ -132,7 +136,13 @@ int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, g
  * edges (rows,64), U (rows,K) uniforms in [0,1) -> edge_feat (rows,K), dist (rows,K).  K <= 15.
  * U == NULL: the uniforms are generated inside the kernel — element row*K + k is element
  * philox_offset (+ *offset_dev if not NULL) + row*K + k of the Philox stream `seed`, exactly what
- * gn_philox_uniform_f32 would have written into U. */
+ * gn_philox_uniform_f32 would have written into U.
+ * Symmetric pairwise form (sym_N = N > 0): rows = B*N(N+1)/2 unordered pairs.  The MLPs run once per
+ * pair; the Gumbel softmax runs for BOTH ordered edges (i,j) and (j,i) with their own uniforms
+ * (U / Philox positions are those of the ordered (B,N*N,K) tensor).  dist (B*N*N,K) receives the ordered
+ * distributions (may be NULL when the caller does not need them); edge_feat (rows,K) receives
+ * fac*(dist_ij + dist_ji) (2*fac*dist_ii on the diagonal) — exactly the weight the pair carries in the
+ * edge->node sum, where both ordered edges meet the same typed MLP output. */
 typedef struct {
   const float* edges;
   const float* U;
@@ -143,18 +153,21 @@ typedef struct {
   unsigned long long philox_offset;
   int rows;
   int K;
+  int sym_N;
 } gn_edge_group_t;
 int gn_edge_mlp_gumbel_f32(const gn_edge_group_t* groups, int n_groups, float tau, unsigned long long seed,
                            const unsigned long long* offset_dev, gn_stream_t stream);
 
 /* ---- A5: hyperedge aggregation --------------------------------------------------------------
  * gather: eo = H ori            (edge_aggregation.forward, MS_HGNN_batch.py:263)
- * H == NULL: pairwise graph (E = N*N), eo[(i,j)] = ori_i + ori_j.   ori (B,N,64) -> eo (B,E,64). */
+ * H == NULL: pairwise graph (E = N*N), eo[(i,j)] = ori_i + ori_j; with sym = 1 only the
+ * E = N(N+1)/2 unordered pairs.   ori (B,N,64) -> eo (B,E,64). */
 typedef struct {
   const float* ori;
   const float* H;
   float* eo;
   int E;
+  int sym;
 } gn_gather_group_t;
 int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, int B, int N, gn_stream_t stream);
 
@@ -175,13 +188,15 @@ int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t strea
 
 /* scatter: out = cat(H^T feat, ori) / divisor     (MS_HGNN_batch.py:267; divisor = N gives the
  * division of edge2node :120,355, divisor = 1 the bare edge_aggregation.forward).
- * feat (B,E,64), ori (B,N,64) -> out (B,N,128).  H == NULL: pairwise (E = N*N). */
+ * feat (B,E,64), ori (B,N,64) -> out (B,N,128).  H == NULL: pairwise (E = N*N); with sym = 1 feat
+ * holds the E = N(N+1)/2 pair sums (see gn_edge_mlp_gumbel_f32) and node n adds the N pairs {n,j}. */
 typedef struct {
   const float* feat;
   const float* H;
   const float* ori;
   float* out;
   int E;
+  int sym;
 } gn_scatter_group_t;
 int gn_agg_scatter_f32(const gn_scatter_group_t* groups, int n_groups, int B, int N, float divisor,
                        gn_stream_t stream);

@@ -434,3 +434,61 @@ def test_in_kernel_philox_equals_uniform_tensor():
     assert torch.equal(ef_a, ef_b) and torch.equal(d_a, d_b)
     ef_c, _ = ops.edge_mlp_gumbel(edges, ops.PhiloxNoise(77, 124, ctr), pk, K)
     assert not torch.equal(ef_a, ef_c)
+
+
+def _pairs(N):
+    return [(i, j) for i in range(N) for j in range(i, N)]
+
+
+@pytest.mark.parametrize("B,N", [(5, 11), (2, 50), (3, 1), (1, 3)])
+def test_symmetric_pairwise_stages_equal_ordered_ones(B, N):
+    """The pairwise graph is symmetric; the engine runs its per-edge MLPs once per unordered pair.
+    Each symmetric stage must agree with the ordered stage it replaces."""
+    from groupnet_amd import ops
+    torch.manual_seed(31 + N)
+    pair, _ = build_modules(1)
+    pair.to(dev())
+    with torch.no_grad():
+        for p in pair.attention_mlp.parameters():
+            p.mul_(4.0)
+    h = torch.randn(B, N, 64, device=dev())
+    pk = pair._packed_n2e(0)
+    xp, pq = ops.node_mlp(h, pk)
+    P = ops.pair_count(N)
+    pr = _pairs(N)
+    assert len(pr) == P
+    idx_ij = torch.tensor([i * N + j for i, j in pr], device=dev())
+    idx_ji = torch.tensor([j * N + i for i, j in pr], device=dev())
+    diag = torch.tensor([i == j for i, j in pr], device=dev())
+    # node -> edge
+    e_ord = ops.node2edge(xp, pq, None, pk["w2"], pk["b2"])
+    e_sym = ops.node2edge(xp, pq, None, pk["w2"], pk["b2"], sym=True)
+    assert e_sym.shape == (B, P, 64)
+    assert maxerr(e_sym, e_ord[:, idx_ij]) <= 1e-6 and maxerr(e_sym, e_ord[:, idx_ji]) <= 1e-6
+    # gather
+    g_ord = ops.agg_gather(h, None)
+    g_sym = ops.agg_gather(h, None, sym=True)
+    assert torch.equal(g_sym, g_ord[:, idx_ij])
+    # edge MLP + gumbel: ordered distributions identical, pair weight = sum of the two ordered ones
+    K = pair.edge_types
+    U = torch.rand(B, N * N, K, device=dev())
+    spk = pair.nmp_mlp_start._packed()
+    ef_ord, d_ord = ops.edge_mlp_gumbel(e_ord, U, spk, K)
+    (ef_sym, d_sym), = ops.edge_mlp_gumbel_grouped([(e_sym, U, spk, K, N, True)])
+    assert d_sym.shape == (B, N * N, K) and ef_sym.shape == (B, P, K)
+    assert maxerr(d_sym, d_ord) <= 1e-6
+    want = torch.where(diag[None, :, None], 2 * ef_ord[:, idx_ij], ef_ord[:, idx_ij] + ef_ord[:, idx_ji])
+    assert maxerr(ef_sym, want) <= 1e-6
+    # in-kernel Philox in the symmetric form reads the ordered stream positions
+    Uph = ops.philox_uniform((B, N * N, K), 5, 17, dev())
+    (ef_a, d_a), = ops.edge_mlp_gumbel_grouped([(e_sym, Uph, spk, K, N, True)])
+    (ef_b, d_b), = ops.edge_mlp_gumbel_grouped([(e_sym, ops.PhiloxNoise(5, 17), spk, K, N, True)])
+    assert torch.equal(ef_a, ef_b) and torch.equal(d_a, d_b)
+    (ef_c, d_c), = ops.edge_mlp_gumbel_grouped([(e_sym, Uph, spk, K, N, False)])
+    assert d_c is None and torch.equal(ef_c, ef_a)
+    # scatter: pair sums == ordered sums
+    f_ord = torch.randn(B, N * N, 64, device=dev())
+    f_pair = torch.where(diag[None, :, None], 2 * f_ord[:, idx_ij], f_ord[:, idx_ij] + f_ord[:, idx_ji])
+    s_ord = ops.agg_scatter(f_ord, None, h)
+    s_sym = ops.agg_scatter(f_pair, None, h, sym=True)
+    assert maxerr(s_sym, s_ord) <= 1e-5
