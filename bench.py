@@ -214,7 +214,7 @@ def main():
             # ---- north_star: hyperedge aggregation gather+scatter vs HBM at N=11 / B=4096 ----------------
             Bb = 4096
             ori = torch.randn(Bb, N, 64, device=dev)
-            _, Hs = ops.affinity_topk(ori, [5], want_corr=False)
+            _, Hs, _ = ops.affinity_topk(ori, [5], want_corr=False)
             H = Hs[0]
             feat = torch.randn(Bb, N, 64, device=dev)
             t_g = time_kernel_ms(lambda: ops.agg_gather(ori, H))

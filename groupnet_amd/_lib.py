@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -55,6 +55,10 @@ class Mlp2Group(ctypes.Structure):      # gn_mlp2_group_t
     _fields_ = [("x", _P), ("W", _P), ("bias", _P), ("y", _P)]
 
 
+class BlockExtras(ctypes.Structure):    # gn_block_extras_t
+    _fields_ = [("f_out", _P), ("f_out_ld", _I), ("H_cat", _P), ("counter", _P), ("counter_add", _U64)]
+
+
 MAX_GROUPS = 10
 
 # name -> (restype, argtypes); mirrors include/groupnet_hip.h one to one
@@ -63,7 +67,8 @@ SIGNATURES = {
     "gn_strerror": (ctypes.c_char_p, [_I]),
     "gn_affinity_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "gn_topk_incidence_f32": (_I, [_P, ctypes.POINTER(_P), ctypes.POINTER(_I), _I, _I, _I, _P]),
-    "gn_affinity_topk_f32": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_I), _I, _I, _I, _I, _P]),
+    "gn_affinity_topk_f32": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_I), _I, _I, _I, _I,
+                                  ctypes.POINTER(BlockExtras), _P]),
     "gn_packed_elems": (_SZ, [_I, _I]),
     "gn_pack_linear_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "gn_node_mlp_f32": (_I, [ctypes.POINTER(NodeGroup), _I, _I, _P]),

@@ -25,6 +25,10 @@ struct ScaleList {
   float* H[GN_MAX_SCALES];
   int k[GN_MAX_SCALES];  // clamped to >= 1; k == N marks the single all-ones hyperedge
   int n;
+  // optional second destination: the (B, cat_rows, N) concatenation of every H_s (scale s at row cat_off[s])
+  float* H_cat;
+  int cat_off[GN_MAX_SCALES];
+  int cat_rows;
 };
 
 // rank of column c inside `row` (LDS, N entries) and the writes of every scale
@@ -34,9 +38,14 @@ __device__ __forceinline__ void emit_incidence(const float* row, int N, int b, i
   for (int j = 0; j < N; ++j) rank += beats(row[j], j, v, c) ? 1 : 0;
   for (int s = 0; s < sl.n; ++s) {
     if (sl.k[s] == N) {
-      if (i == 0) sl.H[s][(size_t)b * N + c] = 1.f;
+      if (i == 0) {
+        sl.H[s][(size_t)b * N + c] = 1.f;
+        if (sl.H_cat) sl.H_cat[((size_t)b * sl.cat_rows + sl.cat_off[s]) * N + c] = 1.f;
+      }
     } else {
-      sl.H[s][((size_t)b * N + i) * N + c] = rank < sl.k[s] ? 1.f : 0.f;
+      const float v = rank < sl.k[s] ? 1.f : 0.f;
+      sl.H[s][((size_t)b * N + i) * N + c] = v;
+      if (sl.H_cat) sl.H_cat[((size_t)b * sl.cat_rows + sl.cat_off[s] + i) * N + c] = v;
     }
   }
 }
@@ -45,7 +54,7 @@ __device__ __forceinline__ void emit_incidence(const float* row, int N, int b, i
 // 16-byte row reads of different rows on different banks), corr is formed in LDS, optionally
 // written out, and ranked in place.  Needs N*(D+4 + N)*4 bytes of LDS.
 __global__ __launch_bounds__(kBlock) void affinity_topk_kernel(const float* __restrict__ f, float* __restrict__ corr,
-                                                               ScaleList sl, int N, int D) {
+                                                               ScaleList sl, int N, int D, gn_block_extras_t ex) {
   extern __shared__ __align__(16) float lds[];
   const int b = blockIdx.x;
   const int ldq = D + 4;
@@ -53,9 +62,12 @@ __global__ __launch_bounds__(kBlock) void affinity_topk_kernel(const float* __re
   float* cr = lds + N * ldq;  // N x N
   const float* fb = f + (size_t)b * N * D;
   const int d4 = D >> 2;
+  if (ex.counter != nullptr && b == 0 && threadIdx.x == 0) *ex.counter += ex.counter_add;
   for (int idx = threadIdx.x; idx < N * d4; idx += kBlock) {
     const int r = idx / d4, cc = idx - r * d4;
-    *reinterpret_cast<f32x4*>(q + r * ldq + 4 * cc) = *reinterpret_cast<const f32x4*>(fb + (size_t)r * D + 4 * cc);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(fb + (size_t)r * D + 4 * cc);
+    *reinterpret_cast<f32x4*>(q + r * ldq + 4 * cc) = v;
+    if (ex.f_out != nullptr) *reinterpret_cast<f32x4*>(ex.f_out + ((size_t)b * N + r) * ex.f_out_ld + 4 * cc) = v;
   }
   __syncthreads();
   // row norms: one wave per row, lanes stride the row
@@ -544,6 +556,7 @@ __global__ __launch_bounds__(kBlock) void philox_uniform_kernel(float* __restric
 }
 
 int fill_scales(ScaleList& sl, float* const* H_list, const int* k_list, int n_scales, int N) {
+  sl = ScaleList{};
   if (n_scales < 0 || n_scales > GN_MAX_SCALES) return GN_ERR_SHAPE;
   if (n_scales > 0 && (H_list == nullptr || k_list == nullptr)) return GN_ERR_NULL;
   sl.n = n_scales;
@@ -552,6 +565,8 @@ int fill_scales(ScaleList& sl, float* const* H_list, const int* k_list, int n_sc
     if (k_list[s] > N) return GN_ERR_K_RANGE;
     sl.H[s] = H_list[s];
     sl.k[s] = k_list[s] == N ? N : (k_list[s] < 1 ? 1 : k_list[s]);
+    sl.cat_off[s] = sl.cat_rows;
+    sl.cat_rows += k_list[s] == N ? 1 : N;
   }
   return GN_OK;
 }
@@ -563,7 +578,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) 
 
 }  // namespace
 
-extern "C" int gn_abi_version(void) { return 5; }
+extern "C" int gn_abi_version(void) { return 6; }
 
 extern "C" const char* gn_strerror(int code) {
   switch (code) {
@@ -585,10 +600,11 @@ extern "C" int gn_affinity_f32(const float* f, float* corr, int B, int N, int D,
   if (B <= 0 || N <= 0 || D <= 0 || (D & 3) || D > 1024) return GN_ERR_SHAPE;
   const size_t fused = (size_t)N * (D + 4 + N) * sizeof(float);
   if (fused <= kLdsBudget) {
-    ScaleList sl;
+    ScaleList sl{};
     sl.n = 0;
     gn_allow_big_lds(affinity_topk_kernel);
-    hipLaunchKernelGGL(affinity_topk_kernel, dim3(B), dim3(kBlock), fused, (hipStream_t)stream, f, corr, sl, N, D);
+    hipLaunchKernelGGL(affinity_topk_kernel, dim3(B), dim3(kBlock), fused, (hipStream_t)stream, f, corr, sl, N, D,
+                       gn_block_extras_t{});
   } else {
     const size_t lds = (size_t)(16 + 64) * (D + 4) * sizeof(float);
     gn_allow_big_lds(affinity_banded_kernel);
@@ -617,7 +633,7 @@ extern "C" int gn_topk_incidence_f32(const float* corr, float* const* H_list, co
 }
 
 extern "C" int gn_affinity_topk_f32(const float* f, float* corr, float* const* H_list, const int* k_list, int n_scales,
-                                    int B, int N, int D, gn_stream_t stream) {
+                                    int B, int N, int D, const gn_block_extras_t* extras, gn_stream_t stream) {
   GN_REQUIRE_PTR(f);
   GN_REQUIRE_ALIGNED(f);
   if (B <= 0 || N <= 0 || D <= 0 || (D & 3) || D > 1024) return GN_ERR_SHAPE;
@@ -626,8 +642,14 @@ extern "C" int gn_affinity_topk_f32(const float* f, float* corr, float* const* H
   if (rc != GN_OK) return rc;
   const size_t fused = (size_t)N * (D + 4 + N) * sizeof(float);
   if (fused > kLdsBudget) return GN_ERR_LDS;
+  gn_block_extras_t ex{};
+  if (extras != nullptr) {
+    ex = *extras;
+    if (ex.f_out != nullptr && (!gn_aligned16(ex.f_out) || ex.f_out_ld < D || (ex.f_out_ld & 3))) return GN_ERR_ALIGN;
+    sl.H_cat = ex.H_cat;
+  }
   gn_allow_big_lds(affinity_topk_kernel);
-  hipLaunchKernelGGL(affinity_topk_kernel, dim3(B), dim3(kBlock), fused, (hipStream_t)stream, f, corr, sl, N, D);
+  hipLaunchKernelGGL(affinity_topk_kernel, dim3(B), dim3(kBlock), fused, (hipStream_t)stream, f, corr, sl, N, D, ex);
   return gn_check_launch();
 }
 

@@ -53,19 +53,18 @@ class GraphedMultiScale:
                         self._step()
                 torch.cuda.current_stream(self.device).wait_stream(side)
                 torch.cuda.synchronize(self.device)
-                self.counter.zero_()
+                # every replay first advances the counter by one step's worth of draws: start one step back
+                self.counter.fill_(-self.draws_per_step)
                 with torch.cuda.graph(self.graph):
                     self.out, self.H = self._step()
         finally:
             _mods.set_noise_mode(prev[0], prev[1], prev[2], prev[3])
 
     def _step(self) -> Tuple[Tensor, Optional[Tensor]]:
-        # offset 0 + device counter: the position is entirely on the device
+        # offset 0 + device counter: the position is entirely on the device; the first launch of the
+        # forward moves the counter past the previous replay's draws
         _mods.set_noise_mode("device", seed=self.seed, offset=0, counter=self.counter)
-        out, H = self.block(self.f_in)
-        # each module drew from [counter + its host-side offset); move the base past all of them
-        ops.counter_add(self.counter, self.draws_per_step)
-        return out, H
+        return self.block(self.f_in, advance=(self.counter, self.draws_per_step))
 
     def __call__(self, f: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
         if f is not None:

@@ -59,9 +59,12 @@ class MultiScaleHGNN(nn.Module):
             out.append((B, 1 if s == N else N, 10))
         return out
 
-    def forward(self, f: Tensor, noise_u: Optional[Sequence] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    def forward(self, f: Tensor, noise_u: Optional[Sequence] = None, advance=None
+                ) -> Tuple[Tensor, Optional[Tensor]]:
         """``noise_u``: optional list with one entry per module (pairwise first), each a tensor or a
-        list of ``nmp_layers`` tensors; default draws as the modules do (reference order)."""
+        list of ``nmp_layers`` tensors; default draws as the modules do (reference order).
+        ``advance`` = (counter, n): add n to the device Philox counter at the START of this forward
+        (used by the captured graph so that every replay draws fresh noise)."""
         _check_forward_only(f)
         ops._req(f, "f", (None, None, self.h_dim))
         B, N, D = f.shape
@@ -73,10 +76,18 @@ class MultiScaleHGNN(nn.Module):
             noise_u = [[_draw_uniform(shp, f.device) for _ in range(nmp)] for shp in self.noise_shapes(B, N)]
         elif len(noise_u) != 1 + S:
             raise ValueError(f"noise_u: need {1 + S} entries (pairwise + one per scale)")
-        corr, Hs = (ops.affinity_topk(f, self.hyper_scales, want_corr=False) if S else (None, []))
         final = torch.empty((B, N, self.out_features), dtype=f.dtype, device=f.device)
-        final[..., :D].copy_(f)
         cols = [final[..., D * (1 + i):D * (2 + i)] for i in range(1 + S)]   # written in place by the last MLP
+        if S:
+            # one launch: affinity, incidence of every scale, f -> final[..., :D], cat(H_s), Philox bump
+            _, Hs, new_H = ops.affinity_topk(f, self.hyper_scales, want_corr=False, f_out=final[..., :D],
+                                             want_H_cat=True, counter=advance[0] if advance else None,
+                                             counter_add=advance[1] if advance else 0)
+        else:
+            Hs, new_H = [], None
+            final[..., :D].copy_(f)
+            if advance:
+                ops.counter_add(advance[0], advance[1])
         mods = [self.interaction, *self.interaction_hyper]
         if self.grouped:
             # every stage of the 1+S modules in ONE launch: launches always carry enough workgroups
@@ -85,5 +96,4 @@ class MultiScaleHGNN(nn.Module):
         else:
             for m, H, u, c in zip(mods, [None, *Hs], noise_u, cols):
                 run_message_passing([m], [f], [H], [u], [c])
-        new_H = torch.cat(Hs, dim=1) if S else None
         return final, new_H

@@ -89,17 +89,37 @@ def topk_incidence(corr: Tensor, scales: Sequence[int]) -> List[Tensor]:
     return Hs
 
 
-def affinity_topk(f: Tensor, scales: Sequence[int], want_corr: bool = True) -> Tuple[Optional[Tensor], List[Tensor]]:
-    """Fused A0+A1: f -> (corr, [H_s]) in one launch."""
+def affinity_topk(f: Tensor, scales: Sequence[int], want_corr: bool = True, f_out: Optional[Tensor] = None,
+                  want_H_cat: bool = False, counter: Optional[Tensor] = None, counter_add: int = 0
+                  ) -> Tuple[Optional[Tensor], List[Tensor], Optional[Tensor]]:
+    """Fused A0+A1: f -> (corr, [H_s], H_cat) in one launch.
+
+    Extras for the multiscale block (no copy kernels after this launch): ``f_out`` — a last-dim slice
+    (B, N, D) of a wider contiguous tensor that also receives f; ``want_H_cat`` — also build
+    cat(H_s, dim=1); ``counter``/``counter_add`` — advance the device Philox position."""
     _req(f, "f", (None, None, None))
     B, N, D = f.shape
     corr = torch.empty((B, N, N), dtype=f.dtype, device=f.device) if want_corr else None
     Hs = _alloc_incidence(B, N, scales, f)
     Hl, kl, n = _scale_args(Hs, scales)
+    ex = _lib.BlockExtras()
+    H_cat = None
+    if f_out is not None:
+        if not (f_out.is_cuda and f_out.dtype == torch.float32 and tuple(f_out.shape) == (B, N, D)
+                and f_out.stride(2) == 1 and f_out.stride(0) == N * f_out.stride(1)):
+            raise ValueError("f_out: a (B,N,D) last-dim slice of a contiguous float32 GPU tensor")
+        ex.f_out, ex.f_out_ld = f_out.data_ptr(), f_out.stride(1)
+    if want_H_cat:
+        H_cat = torch.empty((B, sum(h.shape[1] for h in Hs), N), dtype=f.dtype, device=f.device)
+        ex.H_cat = H_cat.data_ptr()
+    if counter is not None:
+        if not (counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1):
+            raise ValueError("counter: a 1-element int64 GPU tensor")
+        ex.counter, ex.counter_add = counter.data_ptr(), int(counter_add) & (2**64 - 1)
     with torch.cuda.device(f.device):
-        check(load().gn_affinity_topk_f32(_ptr(f), _ptr(corr), Hl, kl, n, B, N, D, stream_handle()),
+        check(load().gn_affinity_topk_f32(_ptr(f), _ptr(corr), Hl, kl, n, B, N, D, ctypes.byref(ex), stream_handle()),
               "gn_affinity_topk_f32")
-    return corr, Hs
+    return corr, Hs, H_cat
 
 
 # ---- weight packing ------------------------------------------------------------------------------

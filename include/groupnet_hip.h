@@ -65,9 +65,24 @@ int gn_topk_incidence_f32(const float* corr, float* const* H_list, const int* k_
                           int B, int N, gn_stream_t stream);
 
 /* A0+A1 fused: f -> corr (may be NULL: not written) and every H_s, without re-reading corr
- * from HBM.  Same contracts as the two functions above; N*(N+D)*4 bytes must fit in LDS. */
+ * from HBM.  Same contracts as the two functions above; N*(N+D)*4 bytes must fit in LDS.
+ * `extras` (may be NULL) lets this first launch of a multiscale forward also produce what the
+ * caller's concatenations need, so that no copy kernels follow (model/GroupNet_nba.py:296-311):
+ *   f_out   : f is also written to f_out with row stride f_out_ld floats (the first D columns of
+ *             the concatenated feature tensor);
+ *   H_cat   : every H_s is also written into the (B, sum_s E_s, N) concatenation, scale order;
+ *   counter : *counter += counter_add by one thread (advances the device Philox position once per
+ *             forward, see gn_edge_mlp_gumbel_f32) — ordered before every later launch of the stream. */
+typedef struct {
+  float* f_out;
+  int f_out_ld;
+  float* H_cat;
+  unsigned long long* counter;
+  unsigned long long counter_add;
+} gn_block_extras_t;
 int gn_affinity_topk_f32(const float* f, float* corr, float* const* H_list, const int* k_list,
-                         int n_scales, int B, int N, int D, gn_stream_t stream);
+                         int n_scales, int B, int N, int D, const gn_block_extras_t* extras,
+                         gn_stream_t stream);
 
 /* ---- weight packing -------------------------------------------------------------------
  * Number of floats of the packed image of an (out x in) nn.Linear weight. */
