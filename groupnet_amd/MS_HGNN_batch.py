@@ -32,6 +32,7 @@ from . import ops
 Tensor = torch.Tensor
 _HDIM_EXTEND = 64      # model/MS_HGNN_batch.py:72,292
 _GUMBEL_TAU = 0.5      # model/MS_HGNN_batch.py:45
+_FUSED_GATHER_MAX_N = 64   # beyond this the LDS-tiled standalone gather beats a per-lane scan of H rows
 
 
 # ---------------------------------------------------------------------------------------------
@@ -351,8 +352,15 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
 
     def edge2node(edge_feats: Sequence[Tensor], oris: Sequence[Tensor], idx: int) -> List[Tensor]:
         aggs = [m.edge_aggregation_list[idx] for m in mods]
-        eos = ops.agg_gather_grouped(list(zip(oris, Hs, syms)))
+        if N <= _FUSED_GATHER_MAX_N:
+            # eo = H @ ori is formed inside the typed-MLP kernel (it never exists in HBM)
+            eos = [ops.GatherSpec(o, H, sy) for o, H, sy in zip(oris, Hs, syms)]
+        else:
+            eos = ops.agg_gather_grouped(list(zip(oris, Hs, syms)))
         feats = ops.agg_mlp_grouped([(eo, ef, a._packed(), a.edge_types) for eo, ef, a in zip(eos, edge_feats, aggs)])
+        if N <= _FUSED_GATHER_MAX_N:
+            # cat(H^T feat, ori) / N is formed inside the MLP kernel that consumes it
+            return [ops.ScatterSpec(f, H, o, sy) for f, H, o, sy in zip(feats, Hs, oris, syms)]
         return ops.agg_scatter_grouped([(f, H, o, sy) for f, H, o, sy in zip(feats, Hs, oris, syms)])
 
     res = edge_mlp([m.nmp_mlp_start for m in mods], node2edge(hs, 0), True)

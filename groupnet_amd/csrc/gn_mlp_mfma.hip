@@ -113,9 +113,12 @@ __device__ __forceinline__ void ring_prime(WRing& ring, const f32x4* __restrict_
 struct NoSide {
   __device__ __forceinline__ void operator()(int) const {}
 };
-template <int IT, int START = 0, typename Side = NoSide>
+// LN: length in steps of the chunk at `nxt` when it is shorter than the ring (kP); the steps after it then
+// come from `nxt2`.
+template <int IT, int START = 0, typename Side = NoSide, int LN = kP>
 __device__ __forceinline__ void mma_tile(const f32x4* __restrict__ cur, const f32x4* __restrict__ nxt, WRing& ring,
-                                         const f32x16 (&in)[IT], f32x16& acc, Side side = Side()) {
+                                         const f32x16 (&in)[IT], f32x16& acc, Side side = Side(),
+                                         const f32x4* __restrict__ nxt2 = nullptr) {
   constexpr int S = 4 * IT;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -127,7 +130,12 @@ __device__ __forceinline__ void mma_tile(const f32x4* __restrict__ cur, const f3
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], in[t][4 * q + 2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], in[t][4 * q + 3], acc, 0, 0, 0);
     side(s);
-    ring.s[slot] = (s + kP < S) ? cur[(s + kP) * kStep] : nxt[(s + kP - S) * kStep];
+    if (s + kP < S)
+      ring.s[slot] = cur[(s + kP) * kStep];
+    else if (s + kP - S < LN)
+      ring.s[slot] = nxt[(s + kP - S) * kStep];
+    else
+      ring.s[slot] = nxt2[(s + kP - S - LN) * kStep];
     // hipcc otherwise sinks the run-ahead load down to its use and collapses the ring to depth 1-2
 #if !defined(GN_EXP_NO_SCHED_BARRIER)
     __builtin_amdgcn_sched_barrier(0);
@@ -358,6 +366,48 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge
 //             which is what lets the chip's 1024 SIMDs finish together (one 6-type unit is ~47 us);
 //   wpr = 4 : groups with fewer row blocks than SIMDs (the hyper modules at B*N rows): 4x shorter
 //             critical path.
+// Input rows of the typed MLP formed on the fly (fused gather): lane (j,h) accumulates its 32 features
+// of row r = b*E + e from the member nodes' ori rows.
+__device__ __forceinline__ void add_row(const float* __restrict__ src, float w, int h, f32x16 (&a)[2]) {
+  const float* p = src + 4 * h;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + 32 * t + 8 * q);
+      a[t][4 * q + 0] = fmaf(w, v[0], a[t][4 * q + 0]);
+      a[t][4 * q + 1] = fmaf(w, v[1], a[t][4 * q + 1]);
+      a[t][4 * q + 2] = fmaf(w, v[2], a[t][4 * q + 2]);
+      a[t][4 * q + 3] = fmaf(w, v[3], a[t][4 * q + 3]);
+    }
+}
+__device__ __forceinline__ void gather_rows(const gn_agg_group_t& G, int row, int h, f32x16 (&a)[2]) {
+  const int E = G.E, N = G.N;
+  const int b = row / E, e = row - b * E;
+  const float* ob = G.ori + (size_t)b * N * GN_FEAT;
+  if (G.H == nullptr) {
+    int i, j;
+    if (G.sym) {
+      gn_pair_decode(e, N, i, j);
+    } else {
+      i = e / N;
+      j = e - i * N;
+    }
+    load_rows<2>(ob, GN_FEAT, i, h, a);           // ori_i
+    add_row(ob + (size_t)j * GN_FEAT, 1.f, h, a);  // + ori_j  (2 ori_i on the diagonal)
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[t][r] = 0.f;
+    const float* hrow = G.H + (size_t)row * N;
+    for (int n = 0; n < N; ++n) {
+      const float hv = hrow[n];
+      if (hv != 0.f) add_row(ob + (size_t)n * GN_FEAT, hv, h, a);
+    }
+  }
+}
+
 constexpr int kTypeSteps = 64;
 struct AggGroup {
   gn_agg_group_t a;
@@ -389,7 +439,10 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
   const RowBlock rb = row_block(rows, any_rows ? blk : 0);
   const int lane = rb.lane, h = rb.h;
   f32x16 in[2], hid[4], out[2];
-  load_rows<2>(G.eo, GN_FEAT, rb.row_ld, h, in);
+  if (G.eo != nullptr)
+    load_rows<2>(G.eo, GN_FEAT, rb.row_ld, h, in);
+  else
+    gather_rows(G, rb.row_ld, h, in);
 #pragma unroll
   for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -469,11 +522,79 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
   }
 }
 
-// ---- A6 / generic: y = W1 relu(W0 x + b0) + b1, output tiles streamed -----------------------------
+// ---- A6 / generic: y = W1 relu(W0 x + b0) + b1 ----------------------------------------------------
 // W = [W0 (dh x din) | W1 (dout x dh)] packed; bias = [b0 (dh) | b1 padded to a multiple of 32].
-// blockIdx.y = group.
+
+// Input rows of the MLP: read from x, or — fused scatter, IT == 4 — formed on the fly as
+// cat(sum_e H[b,e,n] feat[b,e], ori[b,n]) / divisor  (edge_aggregation.forward + edge2node's / N).
+template <int IT>
+__device__ __forceinline__ void mlp2_rows(const gn_mlp2_group_t& G, int row, int h, int N, float divisor,
+                                          f32x16 (&in)[IT]) {
+  if (G.x != nullptr) {
+    load_rows<IT>(G.x, IT * 32, row, h, in);
+    return;
+  }
+  if constexpr (IT == 4) {
+    const int E = G.E;
+    const int b = row / N, n = row - b * N;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const float* fb = G.feat + (size_t)b * E * GN_FEAT;
+    if (G.H != nullptr) {
+      const float* hcol = G.H + (size_t)b * E * N + n;
+      for (int e = 0; e < E; ++e) {
+        const float hv = hcol[(size_t)e * N];
+        if (hv != 0.f) add_row(fb + (size_t)e * GN_FEAT, hv, h, acc);
+      }
+    } else if (G.sym) {
+      for (int j = 0; j < N; ++j) add_row(fb + (size_t)gn_pair_index(n, j, N) * GN_FEAT, 1.f, h, acc);
+    } else {
+      for (int j = 0; j < N; ++j) {
+        add_row(fb + (size_t)(n * N + j) * GN_FEAT, 1.f, h, acc);
+        add_row(fb + (size_t)(j * N + n) * GN_FEAT, 1.f, h, acc);
+      }
+    }
+    f32x16 o[2];
+    load_rows<2>(G.ori, GN_FEAT, row, h, o);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        in[t][r] = acc[t][r] / divisor;
+        in[2 + t][r] = o[t][r] / divisor;
+      }
+  }
+}
+
+// one output tile (16 registers of this lane) -> y, honouring dout / ldy that are not multiples of 4
+__device__ __forceinline__ void store_out_tile(float* __restrict__ y, int row, int ldy, int dout, int o, int h,
+                                               const f32x16& acc) {
+  float* p = y + (size_t)row * ldy;
+  if (((dout | ldy) & 3) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = 32 * o + 8 * q + 4 * h;
+      if (f < dout) {
+        f32x4 v = {acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(p + f) = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = 32 * o + feat_of(r, h);
+      if (f < dout) p[f] = acc[r];
+    }
+  }
+}
+
+// Whole form: every wave owns a row block, output tiles streamed.  blockIdx.y = group.
 template <int IT, int HT>
-__global__ __launch_bounds__(256) void mlp2_kernel(GroupTable<gn_mlp2_group_t> T, int rows, int dout, int ldy) {
+__global__ __launch_bounds__(256) void mlp2_kernel(GroupTable<gn_mlp2_group_t> T, int rows, int dout, int ldy, int N,
+                                                   float divisor) {
   const int blk = blockIdx.x * 4 + wave_id();
   if (blk * 32 >= rows) return;
   const gn_mlp2_group_t G = T.g[blockIdx.y];
@@ -481,7 +602,7 @@ __global__ __launch_bounds__(256) void mlp2_kernel(GroupTable<gn_mlp2_group_t> T
   Chain c;
   chain_begin(c, G.W, G.bias, rb.lane);
   f32x16 in[IT], hid[HT];
-  load_rows<IT>(G.x, IT * 32, rb.row_ld, rb.h, in);
+  mlp2_rows<IT>(G, rb.row_ld, rb.h, N, divisor, in);
   chain_linear<HT, IT, true>(c, in, hid);
   const int OT = (dout + 31) >> 5;
   constexpr int S = 4 * HT;
@@ -493,24 +614,137 @@ __global__ __launch_bounds__(256) void mlp2_kernel(GroupTable<gn_mlp2_group_t> T
     mma_tile<HT>(c.w, tail ? c.w : c.w + S * kStep, c.ring, hid, acc);
     c.w += S * kStep;
     c.b += 32;
-    if (rb.live) {
-      float* p = G.y + (size_t)rb.row * ldy;
-      if (((dout | ldy) & 3) == 0) {
+    if (rb.live) store_out_tile(G.y, rb.row, ldy, dout, o, rb.h, acc);
+  }
+}
+
+// Split form for few row blocks (fewer waves than SIMDs): the 4 waves of a workgroup share ONE row
+// block.  Wave w computes hidden tile w (HT == 4) and the partial products of every output tile with
+// that slice of the hidden layer; partial sums meet in LDS.  4x shorter critical path; dout <= 64.
+template <int IT>
+__global__ __launch_bounds__(256) void mlp2_split_kernel(GroupTable<gn_mlp2_group_t> T, int rows, int dout, int ldy,
+                                                         int N, float divisor) {
+  constexpr int HT = 4;
+  __shared__ float part[4][32][64];
+  const gn_mlp2_group_t G = T.g[blockIdx.y];
+  const int wave = wave_id();
+  const RowBlock rb = row_block(rows, blockIdx.x);
+  const int lane = rb.lane, h = rb.h;
+  const int OT = (dout + 31) >> 5;  // 1 or 2
+  f32x16 in[IT], hid[1], out[2];
+  const f32x4* Wl = reinterpret_cast<const f32x4*>(G.W) + lane;
+  const f32x4* tile = Wl + (size_t)wave * (4 * IT) * kStep;                 // W0 tile `wave`
+  const f32x4* w1 = Wl + (size_t)HT * (4 * IT) * kStep;                     // W1: tile (o, t) at (o*HT + t)*4 steps
+  const f32x4* sl0 = w1 + (size_t)(0 * HT + wave) * 4 * kStep;
+  const f32x4* sl1 = w1 + (size_t)((OT > 1 ? 1 : 0) * HT + wave) * 4 * kStep;
+  WRing ring;
+  ring_prime(ring, tile);
+  hid[0] = load_bias_tile(G.bias + 32 * wave, h);
+  mlp2_rows<IT>(G, rb.row_ld, h, N, divisor, in);
+  mma_tile<IT, 0, NoSide, 4>(tile, sl0, ring, in, hid[0], NoSide(), sl1);
+  relu16(hid[0]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int f = 32 * o + 8 * q + 4 * rb.h;
-          if (f < dout) {
-            f32x4 v = {acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-            *reinterpret_cast<f32x4*>(p + f) = v;
-          }
-        }
-      } else {
+  for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int f = 32 * o + feat_of(r, rb.h);
-          if (f < dout) p[f] = acc[r];
-        }
+    for (int r = 0; r < 16; ++r) out[o][r] = 0.f;
+  constexpr int ST = (4 * IT) % kP;  // ring slot after the tile
+  mma_tile<1, ST, NoSide, 4>(sl0, sl1, ring, hid, out[0], NoSide(), sl1);
+  if (OT > 1) mma_tile<1, (ST + 4) % kP, NoSide, 4>(sl1, sl1, ring, hid, out[1], NoSide(), sl1);
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][16 * o + r][lane] = out[o][r];
+  __syncthreads();
+  if (!rb.live) return;
+  // wave w finishes 4*OT registers: the q = w quarter of every output tile
+  const float* b1 = G.bias + 32 * HT;
+  for (int o = 0; o < OT; ++o) {
+    const int reg0 = 16 * o + 4 * wave;
+    const int f = 32 * o + 8 * wave + 4 * h;
+    float v[4];
+#pragma unroll
+    for (int cidx = 0; cidx < 4; ++cidx)
+      v[cidx] = b1[f + cidx] + ((part[0][reg0 + cidx][lane] + part[1][reg0 + cidx][lane]) +
+                                 (part[2][reg0 + cidx][lane] + part[3][reg0 + cidx][lane]));
+    float* p = G.y + (size_t)rb.row * ldy;
+    if (((dout | ldy) & 3) == 0) {
+      if (f < dout) {
+        f32x4 vv = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p + f) = vv;
       }
+    } else {
+#pragma unroll
+      for (int cidx = 0; cidx < 4; ++cidx)
+        if (f + cidx < dout) p[f + cidx] = v[cidx];
+    }
+  }
+}
+
+// ---- A3 first half, split form: 4 waves per row block -------------------------------------------------
+// Wave w computes hidden tiles 2w, 2w+1 of the 64->256 layer and the partial 256->64 products over
+// that quarter of the hidden layer; the partial x' tiles meet in LDS; waves 0 and 1 then finish x'
+// (+ bias), store it and apply the 64->64 pq projection (one output tile each).
+__global__ __launch_bounds__(256) void node_mlp_split_kernel(GroupTable<gn_node_group_t> T, int rows) {
+  __shared__ float part[4][32][64];
+  const gn_node_group_t G = T.g[blockIdx.y];
+  const int wave = wave_id();
+  const RowBlock rb = row_block(rows, blockIdx.x);
+  const int lane = rb.lane, h = rb.h;
+  const f32x4* Wl = reinterpret_cast<const f32x4*>(G.W) + lane;
+  const f32x4* w0 = Wl + (size_t)(2 * wave) * 8 * kStep;                   // W0 tiles 2w, 2w+1 (8 steps each)
+  const f32x4* w1 = Wl + (size_t)8 * 8 * kStep;                            // W1 tile (o, t) at (o*8 + t)*4 steps
+  const f32x4* w1a = w1 + (size_t)(0 * 8 + 2 * wave) * 4 * kStep;          // (0,2w),(0,2w+1): 8 steps
+  const f32x4* w1b = w1 + (size_t)(1 * 8 + 2 * wave) * 4 * kStep;          // (1,2w),(1,2w+1): 8 steps
+  const f32x4* wpq = w1 + (size_t)2 * 8 * 4 * kStep + (size_t)(wave & 1) * 8 * kStep;  // Wpq tile w (8 steps)
+  const float* b0 = G.bias;
+  const float* b1 = G.bias + 256;
+  const float* bpq = G.bias + 320;
+  WRing ring;
+  ring_prime(ring, w0);
+  f32x16 in[2], hid[2], o1[2];
+  hid[0] = load_bias_tile(b0 + 32 * (2 * wave), h);
+  hid[1] = load_bias_tile(b0 + 32 * (2 * wave + 1), h);
+  load_rows<2>(G.x, GN_FEAT, rb.row_ld, h, in);
+  mma_tile<2>(w0, w0 + 8 * kStep, ring, in, hid[0]);
+  mma_tile<2>(w0 + 8 * kStep, w1a, ring, in, hid[1], [&](int s) {
+    if (s == 1) relu16(hid[0]);
+  });
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o1[o][r] = 0.f;
+  mma_tile<2>(w1a, w1b, ring, hid, o1[0], [&](int s) {
+    if (s == 1) relu16(hid[1]);   // hid[1] is first read at step 4
+  });
+  mma_tile<2>(w1b, wpq, ring, hid, o1[1]);
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][16 * o + r][lane] = o1[o][r];
+  __syncthreads();
+  if (wave >= 2) return;
+  // full x' in the MFMA operand layout: bias + the four partial sums
+  f32x16 xp[2];
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    xp[o] = load_bias_tile(b1 + 32 * o, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      xp[o][r] += (part[0][16 * o + r][lane] + part[1][16 * o + r][lane]) +
+                  (part[2][16 * o + r][lane] + part[3][16 * o + r][lane]);
+  }
+  f32x16 pq = load_bias_tile(bpq + 32 * wave, h);
+  mma_tile<2>(wpq, wpq, ring, xp, pq);
+  if (rb.live) {
+    float* px = G.xp + (size_t)rb.row * GN_FEAT + 4 * h + 32 * wave;
+    float* pp = G.pq + (size_t)rb.row * GN_FEAT + 4 * h + 32 * wave;
+    const f32x16 mine = wave == 0 ? xp[0] : xp[1];   // a select, not a runtime-indexed register array
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {mine[4 * q + 0], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]};
+      *reinterpret_cast<f32x4*>(px + 8 * q) = v;
+      f32x4 u = {pq[4 * q + 0], pq[4 * q + 1], pq[4 * q + 2], pq[4 * q + 3]};
+      *reinterpret_cast<f32x4*>(pp + 8 * q) = u;
     }
   }
 }
@@ -565,7 +799,11 @@ extern "C" int gn_node_mlp_f32(const gn_node_group_t* groups, int n_groups, int 
     for (const void* p : ptrs) GN_CHECK(need(p, true));
     T.g[g] = G;
   }
-  hipLaunchKernelGGL(node_mlp_kernel, dim3(row_grid(rows), n_groups), dim3(256), 0, (hipStream_t)stream, T, rows);
+  const int blocks32 = (rows + 31) / 32;
+  if ((long long)blocks32 * n_groups <= 1024)   // fewer row blocks than SIMDs: 4 waves per row block
+    hipLaunchKernelGGL(node_mlp_split_kernel, dim3(blocks32, n_groups), dim3(256), 0, (hipStream_t)stream, T, rows);
+  else
+    hipLaunchKernelGGL(node_mlp_kernel, dim3(row_grid(rows), n_groups), dim3(256), 0, (hipStream_t)stream, T, rows);
   return gn_check_launch();
 }
 
@@ -602,7 +840,14 @@ extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_str
   int wg = 0;
   for (int g = 0; g < n_groups; ++g) {
     const gn_agg_group_t& G = groups[g];
-    GN_CHECK(need(G.eo, true));
+    if (G.eo != nullptr) {
+      GN_CHECK(need(G.eo, true));
+    } else {
+      GN_CHECK(need(G.ori, true));
+      if (G.E <= 0 || G.N <= 0 || G.rows % G.E != 0) return GN_ERR_SHAPE;
+      if (G.H == nullptr && G.E != (G.sym ? gn_pair_count(G.N) : G.N * G.N)) return GN_ERR_SHAPE;
+      if (G.H != nullptr && G.sym) return GN_ERR_SHAPE;
+    }
     GN_CHECK(need(G.W, true));
     GN_CHECK(need(G.b1, true));
     GN_CHECK(need(G.feat, true));
@@ -628,29 +873,54 @@ extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_str
 }
 
 extern "C" int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
-                           gn_stream_t stream) {
+                           int N, float divisor, gn_stream_t stream) {
   GN_CHECK(check_groups(groups, n_groups));
   if (rows <= 0 || dout <= 0 || ldy < dout) return GN_ERR_SHAPE;
   GroupTable<gn_mlp2_group_t> T{};
   T.n = n_groups;
   for (int g = 0; g < n_groups; ++g) {
     const gn_mlp2_group_t& G = groups[g];
-    GN_CHECK(need(G.x, true));
+    if (G.x != nullptr) {
+      GN_CHECK(need(G.x, true));
+    } else {
+      if (din != 128 || N <= 0 || !(divisor != 0.f) || rows % N != 0 || G.E <= 0) return GN_ERR_SHAPE;
+      GN_CHECK(need(G.feat, true));
+      GN_CHECK(need(G.ori, true));
+      if (G.H == nullptr && G.E != (G.sym ? gn_pair_count(N) : N * N)) return GN_ERR_SHAPE;
+      if (G.H != nullptr && G.sym) return GN_ERR_SHAPE;
+    }
     GN_CHECK(need(G.W, true));
     GN_CHECK(need(G.bias, true));
     GN_CHECK(need(G.y, false));
     T.g[g] = G;
   }
-  const dim3 grid(row_grid(rows), n_groups), block(256);
+  const dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
+  const int blocks32 = (rows + 31) / 32;
+  bool fused = false;
+  for (int g = 0; g < n_groups; ++g) fused = fused || groups[g].x == nullptr;
+  int use_split = (dh == 128 && dout <= 64 && (long long)blocks32 * n_groups <= 1024 && (din == 64 || din == 128) &&
+                   !fused)   // the fused-scatter prologue would be repeated by all 4 waves of a row block
+                      ? 1
+                      : 0;
+  if (const char* e = getenv("GN_MLP2_SPLIT")) use_split = atoi(e) != 0 && dh == 128 && dout <= 64;
+  if (use_split) {
+    const dim3 grid(blocks32, n_groups);
+    if (din == 64)
+      hipLaunchKernelGGL((mlp2_split_kernel<2>), grid, block, 0, s, T, rows, dout, ldy, N, divisor);
+    else
+      hipLaunchKernelGGL((mlp2_split_kernel<4>), grid, block, 0, s, T, rows, dout, ldy, N, divisor);
+    return gn_check_launch();
+  }
+  const dim3 grid(row_grid(rows), n_groups);
   if (din == 64 && dh == 128)
-    hipLaunchKernelGGL((mlp2_kernel<2, 4>), grid, block, 0, s, T, rows, dout, ldy);
+    hipLaunchKernelGGL((mlp2_kernel<2, 4>), grid, block, 0, s, T, rows, dout, ldy, N, divisor);
   else if (din == 64 && dh == 256)
-    hipLaunchKernelGGL((mlp2_kernel<2, 8>), grid, block, 0, s, T, rows, dout, ldy);
+    hipLaunchKernelGGL((mlp2_kernel<2, 8>), grid, block, 0, s, T, rows, dout, ldy, N, divisor);
   else if (din == 128 && dh == 128)
-    hipLaunchKernelGGL((mlp2_kernel<4, 4>), grid, block, 0, s, T, rows, dout, ldy);
+    hipLaunchKernelGGL((mlp2_kernel<4, 4>), grid, block, 0, s, T, rows, dout, ldy, N, divisor);
   else if (din == 128 && dh == 256)
-    hipLaunchKernelGGL((mlp2_kernel<4, 8>), grid, block, 0, s, T, rows, dout, ldy);
+    hipLaunchKernelGGL((mlp2_kernel<4, 8>), grid, block, 0, s, T, rows, dout, ldy, N, divisor);
   else
     return GN_ERR_SHAPE;
   return gn_check_launch();

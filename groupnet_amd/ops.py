@@ -319,25 +319,48 @@ def agg_gather(ori: Tensor, H: Optional[Tensor], sym: bool = False) -> Tensor:
     return agg_gather_grouped([(ori, H, sym)])[0]
 
 
-def agg_mlp_grouped(items: Sequence[Tuple[Tensor, Tensor, dict, int]]) -> List[Tensor]:
-    """items = [(eo (B,E,64), edge_feat (B,E,K), pk{"W","b1","b2"}, K)] -> [feat (B,E,64)]."""
+class GatherSpec:
+    """Input rows of the typed MLP to be formed inside the kernel instead of read from an `eo` tensor:
+    eo = H @ ori (H (B,E,N)), or the pairwise rows ori_i + ori_j (H=None; sym -> unordered pairs)."""
+    __slots__ = ("ori", "H", "sym")
+
+    def __init__(self, ori: Tensor, H: Optional[Tensor], sym: bool = False):
+        self.ori, self.H, self.sym = ori, H, bool(sym)
+
+
+def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[Tensor]:
+    """items = [(eo (B,E,64) or GatherSpec, edge_feat (B,E,K), pk{"W","b1","b2"}, K)] -> [feat (B,E,64)]."""
     _groups(len(items))
-    e0 = items[0][0]
     arr = (_lib.AggGroup * len(items))()
     outs = []
     flops = 0
+    dev0 = None
     for g, (eo, edge_feat, pk, K) in enumerate(items):
-        _req(eo, "eo", (None, None, FEAT))
-        B, E, _ = eo.shape
+        if isinstance(eo, GatherSpec):
+            ori, H = eo.ori, eo.H
+            _req(ori, "ori", (None, None, FEAT))
+            B, N, _ = ori.shape
+            E = _edge_count(H, B, N, eo.sym)
+            _same_device(ori, H, edge_feat)
+            like, eo_ptr = ori, 0
+            extra = (ori.data_ptr(), 0 if H is None else H.data_ptr(), E, N, int(eo.sym))
+        else:
+            _req(eo, "eo", (None, None, FEAT))
+            B, E, _ = eo.shape
+            _same_device(eo, edge_feat)
+            like, eo_ptr = eo, eo.data_ptr()
+            extra = (0, 0, 0, 0, 0)
+        dev0 = dev0 or like.device
+        if like.device != dev0:
+            raise ValueError("grouped launch: every group must be on the same device")
         _req(edge_feat, "edge_feat", (B, E, K))
-        _same_device(e0, eo, edge_feat)
-        feat = torch.empty_like(eo)
-        arr[g] = _lib.AggGroup(eo.data_ptr(), edge_feat.data_ptr(), pk["W"].data_ptr(), pk["b1"].data_ptr(),
-                               pk["b2"].data_ptr(), feat.data_ptr(), B * E, K)
+        feat = torch.empty((B, E, FEAT), dtype=like.dtype, device=like.device)
+        arr[g] = _lib.AggGroup(eo_ptr, edge_feat.data_ptr(), pk["W"].data_ptr(), pk["b1"].data_ptr(),
+                               pk["b2"].data_ptr(), feat.data_ptr(), B * E, K, *extra)
         outs.append(feat)
         flops += B * E * K * (2 * 64 * 128 + 2 * 128 * 64 + 2 * 64)
     probe = launch_probe
-    with torch.cuda.device(e0.device):
+    with torch.cuda.device(dev0):
         if probe is not None:
             probe("agg_mlp", flops, True)
         check(load().gn_agg_mlp_f32(arr, len(items), stream_handle()), "gn_agg_mlp_f32")
@@ -381,13 +404,13 @@ def agg_scatter(feat: Tensor, H: Optional[Tensor], ori: Tensor, divisor: Optiona
 
 
 # ---- A6 ------------------------------------------------------------------------------------------
-def _mlp2_out(x: Tensor, dout: int, out: Optional[Tensor]) -> Tuple[Tensor, int]:
+def _mlp2_out(lead: Tuple[int, ...], dout: int, out: Optional[Tensor], like: Tensor) -> Tuple[Tensor, int]:
     if out is None:
-        return torch.empty(tuple(x.shape[:-1]) + (dout,), dtype=x.dtype, device=x.device), dout
-    if not (out.is_cuda and out.dtype == torch.float32 and out.device == x.device):
-        raise ValueError("out: must be a float32 tensor on x's device")
-    if tuple(out.shape) != tuple(x.shape[:-1]) + (dout,) or out.stride(-1) != 1:
-        raise ValueError(f"out: expected shape {tuple(x.shape[:-1]) + (dout,)} with unit inner stride")
+        return torch.empty(tuple(lead) + (dout,), dtype=like.dtype, device=like.device), dout
+    if not (out.is_cuda and out.dtype == torch.float32 and out.device == like.device):
+        raise ValueError("out: must be a float32 tensor on the input's device")
+    if tuple(out.shape) != tuple(lead) + (dout,) or out.stride(-1) != 1:
+        raise ValueError(f"out: expected shape {tuple(lead) + (dout,)} with unit inner stride")
     ldy = out.stride(-2) if out.dim() >= 2 else dout
     for d in range(out.dim() - 2):   # leading dims must be row-contiguous w.r.t. ldy
         if out.stride(d) != out.stride(d + 1) * out.shape[d + 1]:
@@ -395,33 +418,66 @@ def _mlp2_out(x: Tensor, dout: int, out: Optional[Tensor]) -> Tuple[Tensor, int]
     return out, ldy
 
 
-def mlp2_grouped(items: Sequence[Tuple[Tensor, dict, Optional[Tensor]]]) -> List[Tensor]:
-    """items = [(x (..., din), pk{"W","bias","din","dh","dout"}, out or None)], same shapes and row
-    stride for every group.  ``out`` may be a last-dim slice of a contiguous tensor (row stride >
-    dout): the kernel writes the column block in place."""
+class ScatterSpec:
+    """Input rows of a 128-wide MLP to be formed inside the kernel instead of read from a tensor:
+    cat(H^T feat, ori) / divisor (divisor defaults to N) — what agg_scatter would have produced."""
+    __slots__ = ("feat", "H", "ori", "sym", "divisor")
+
+    def __init__(self, feat: Tensor, H: Optional[Tensor], ori: Tensor, sym: bool = False,
+                 divisor: Optional[float] = None):
+        self.feat, self.H, self.ori, self.sym, self.divisor = feat, H, ori, bool(sym), divisor
+
+
+def mlp2_grouped(items: Sequence[Tuple[object, dict, Optional[Tensor]]]) -> List[Tensor]:
+    """items = [(x (..., din) or ScatterSpec, pk{"W","bias","din","dh","dout"}, out or None)], same
+    shapes and row stride for every group.  ``out`` may be a last-dim slice of a contiguous tensor
+    (row stride > dout): the kernel writes the column block in place."""
     _groups(len(items))
-    x0, pk0, _ = items[0]
+    pk0 = items[0][1]
     din, dh, dout = pk0["din"], pk0["dh"], pk0["dout"]
-    _req(x0, "x")
-    if x0.shape[-1] != din:
-        raise ValueError(f"x: last dim {x0.shape[-1]} != {din}")
-    rows = x0.numel() // din
     arr = (_lib.Mlp2Group * len(items))()
-    outs, ld0 = [], None
+    outs, ld0, shape0, dev0, N, divisor = [], None, None, None, 0, 1.0
     for g, (x, pk, out) in enumerate(items):
-        _req(x, "x", tuple(x0.shape))
-        _same_device(x0, x)
         if (pk["din"], pk["dh"], pk["dout"]) != (din, dh, dout):
             raise ValueError("grouped mlp2: every group must have the same layer widths")
-        y, ldy = _mlp2_out(x, dout, out)
+        if isinstance(x, ScatterSpec):
+            if din != 2 * FEAT:
+                raise ValueError("ScatterSpec feeds a 128-wide MLP")
+            _req(x.ori, "ori", (None, None, FEAT))
+            B, Nn, _ = x.ori.shape
+            E = _edge_count(x.H, B, Nn, x.sym)
+            _req(x.feat, "feat", (B, E, FEAT))
+            _same_device(x.ori, x.feat, x.H)
+            d = float(Nn if x.divisor is None else x.divisor)
+            if N and (N, divisor) != (Nn, d):
+                raise ValueError("grouped mlp2: every fused-scatter group must share N and divisor")
+            N, divisor = Nn, d
+            lead, like = (B, Nn), x.ori
+            fields = (0, pk["W"].data_ptr(), pk["bias"].data_ptr(), None, x.feat.data_ptr(),
+                      0 if x.H is None else x.H.data_ptr(), x.ori.data_ptr(), E, int(x.sym))
+        else:
+            _req(x, "x")
+            if x.shape[-1] != din:
+                raise ValueError(f"x: last dim {x.shape[-1]} != {din}")
+            lead, like = tuple(x.shape[:-1]), x
+            fields = (x.data_ptr(), pk["W"].data_ptr(), pk["bias"].data_ptr(), None, 0, 0, 0, 0, 0)
+        if shape0 is None:
+            shape0, dev0 = lead, like.device
+        elif lead != shape0 or like.device != dev0:
+            raise ValueError("grouped mlp2: every group must have the same leading shape and device")
+        y, ldy = _mlp2_out(lead, dout, out, like)
         if ld0 is None:
             ld0 = ldy
         elif ldy != ld0:
             raise ValueError("grouped mlp2: every group must have the same output row stride")
-        arr[g] = _lib.Mlp2Group(x.data_ptr(), pk["W"].data_ptr(), pk["bias"].data_ptr(), y.data_ptr())
+        arr[g] = _lib.Mlp2Group(fields[0], fields[1], fields[2], y.data_ptr(), *fields[4:])
         outs.append(y)
-    with torch.cuda.device(x0.device):
-        check(load().gn_mlp2_f32(arr, len(items), rows, din, dh, dout, ld0, stream_handle()), "gn_mlp2_f32")
+    rows = 1
+    for d_ in shape0:
+        rows *= int(d_)
+    with torch.cuda.device(dev0):
+        check(load().gn_mlp2_f32(arr, len(items), rows, din, dh, dout, ld0, N, divisor, stream_handle()),
+              "gn_mlp2_f32")
     return outs
 
 

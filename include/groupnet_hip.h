@@ -188,7 +188,11 @@ int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, int B, int 
 
 /* typed MLP: feat = sum_k edge_feat[:,k] * MLP^k_{64->128->64}(eo)   (MS_HGNN_batch.py:262,264-265)
  * W: for each type k the packed images [agg_mlp[k].layers.0 (128x64) | agg_mlp[k].layers.1 (64x128)],
- * types back to back; b1 (K,128); b2 (K,64).  eo (rows,64), edge_feat (rows,K) -> feat (rows,64). */
+ * types back to back; b1 (K,128); b2 (K,64).  eo (rows,64), edge_feat (rows,K) -> feat (rows,64).
+ * Fused gather (eo == NULL): the kernel forms its input rows itself from ori (B,N,64) exactly as
+ * gn_agg_gather_f32 would — row r = b*E + e is sum_n H[b,e,n] ori[b,n] (H (B,E,N)), or for the
+ * pairwise graph (H == NULL) ori_i + ori_j with (i,j) the ordered edge (E = N*N) or the unordered
+ * pair (sym = 1, E = N(N+1)/2) — so eo never exists in HBM.  rows must equal B*E. */
 typedef struct {
   const float* eo;
   const float* edge_feat;
@@ -198,6 +202,11 @@ typedef struct {
   float* feat;
   int rows;
   int K;
+  const float* ori;
+  const float* H;
+  int E;
+  int N;
+  int sym;
 } gn_agg_group_t;
 int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream);
 
@@ -222,15 +231,24 @@ int gn_agg_scatter_f32(const gn_scatter_group_t* groups, int n_groups, int B, in
  * din in {64,128}, dh in {128,256}, dout >= 1 (the same for every group).
  * W = packed [W0 (dh x din) | W1 (dout x dh)]; bias = [b0 (dh) | b1 zero-padded to a multiple of 32].
  * x (rows,din) -> y (rows,dout) with row stride ldy >= dout floats (lets the result land in a
- * column block of a wider tensor, e.g. the concatenated per-scale features). */
+ * column block of a wider tensor, e.g. the concatenated per-scale features).
+ * Fused scatter (x == NULL, din == 128): the kernel forms its input rows itself exactly as
+ * gn_agg_scatter_f32 would — row b*N + n is cat(sum_e H[b,e,n] feat[b,e], ori[b,n]) / divisor
+ * (H (B,E,N); H == NULL: the pairwise graph, E = N*N ordered edges or, sym = 1, E = N(N+1)/2 pair
+ * sums) — so the (B,N,128) aggregate never exists in HBM.  rows must equal B*N. */
 typedef struct {
   const float* x;
   const float* W;
   const float* bias;
   float* y;
+  const float* feat;
+  const float* H;
+  const float* ori;
+  int E;
+  int sym;
 } gn_mlp2_group_t;
 int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
-                gn_stream_t stream);
+                int N, float divisor, gn_stream_t stream);
 
 /* ---- device noise (build's own; the reference draws torch.rand on the host) --------------------
  * U[i] = Philox4x32-10(counter = (i + offset) / 4, key = seed)[(i + offset) % 4] >> 8, scaled to

@@ -46,10 +46,13 @@ def test_null_and_shape_errors_do_not_launch():
     assert lib.gn_topk_incidence_f32(P(16), Hs, ks, 1, 2, 11, P(0)) == -3      # k > N
     # grouped stages: descriptors are validated on the host too
     g = (_lib.Mlp2Group * 1)(_lib.Mlp2Group(16, 16, 16, 16))
-    assert lib.gn_mlp2_f32(g, 1, 5, 96, 128, 64, 64, P(0)) == -2            # unsupported widths
-    assert lib.gn_mlp2_f32(g, 0, 5, 128, 128, 64, 64, P(0)) == -2           # no groups
-    assert lib.gn_mlp2_f32(g, 11, 5, 128, 128, 64, 64, P(0)) == -2          # > GN_MAX_GROUPS
-    assert lib.gn_mlp2_f32(None, 1, 5, 128, 128, 64, 64, P(0)) == -1
+    assert lib.gn_mlp2_f32(g, 1, 5, 96, 128, 64, 64, 0, 1.0, P(0)) == -2    # unsupported widths
+    assert lib.gn_mlp2_f32(g, 0, 5, 128, 128, 64, 64, 0, 1.0, P(0)) == -2   # no groups
+    assert lib.gn_mlp2_f32(g, 11, 5, 128, 128, 64, 64, 0, 1.0, P(0)) == -2  # > GN_MAX_GROUPS
+    assert lib.gn_mlp2_f32(None, 1, 5, 128, 128, 64, 64, 0, 1.0, P(0)) == -1
+    g[0].x = 0                                                               # fused scatter needs din=128, N, divisor
+    assert lib.gn_mlp2_f32(g, 1, 22, 64, 128, 64, 64, 11, 11.0, P(0)) == -2
+    assert lib.gn_mlp2_f32(g, 1, 22, 128, 128, 64, 64, 11, 0.0, P(0)) == -2
     a = (_lib.AggGroup * 1)(_lib.AggGroup(16, 16, 16, 16, 16, 16, 5, 17))
     assert lib.gn_agg_mlp_f32(a, 1, P(0)) == -2                             # K > GN_MAX_TYPES
     a[0].K, a[0].W = 6, 8

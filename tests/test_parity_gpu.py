@@ -293,11 +293,15 @@ def test_full_size_properties(B):
             assert nf.shape == (B, N, 64) and fac.shape == (B, N * N, 6)
             assert torch.allclose(fac.sum(-1), torch.ones(B, N * N, device=dev()), atol=1e-5)
             assert bool(torch.isfinite(nf).all())
-            # batch-shard invariance (scenes are independent): halves == whole, bit for bit
+            # batch-shard invariance (scenes are independent): halves == whole.  Bit for bit when both
+            # sizes pick the same kernel forms (the launchers switch to 4-waves-per-row-block forms when a
+            # launch has fewer row blocks than the chip has SIMDs, which changes the summation order).
             half = B // 2
             nf_a, fac_a = pair(h[:half].contiguous(), noise_u=U[:half].contiguous())
             nf_b, fac_b = pair(h[half:].contiguous(), noise_u=U[half:].contiguous())
-            assert torch.equal(torch.cat((nf_a, nf_b)), nf) and torch.equal(torch.cat((fac_a, fac_b)), fac)
+            if B == 512:
+                assert torch.equal(torch.cat((nf_a, nf_b)), nf) and torch.equal(torch.cat((fac_a, fac_b)), fac)
+            assert maxerr(torch.cat((nf_a, nf_b)), nf) <= 1e-6 and maxerr(torch.cat((fac_a, fac_b)), fac) <= 1e-6
             # scene-permutation equivariance
             perm = torch.randperm(B, device=dev())
             nf_p, _ = pair(h[perm].contiguous(), noise_u=U[perm].contiguous())
@@ -310,7 +314,7 @@ def test_full_size_properties(B):
                 assert torch.equal(H2, H)
                 assert torch.allclose(fac.sum(-1), torch.ones(B, E, device=dev()), atol=1e-5)
                 nf_a, _, _ = hyper(h[:half].contiguous(), corr[:half].contiguous(), noise_u=Uh[:half].contiguous())
-                assert torch.equal(nf_a, nf[:half])
+                assert maxerr(nf_a, nf[:half]) <= 1e-6
             # aggregation linearity at full size: gather(a + b) == gather(a) + gather(b) up to rounding
             a, b = torch.randn_like(h), torch.randn_like(h)
             H = Hs[1]
@@ -498,3 +502,62 @@ def test_symmetric_pairwise_stages_equal_ordered_ones(B, N):
     s_ord = ops.agg_scatter(f_ord, None, h)
     s_sym = ops.agg_scatter(f_pair, None, h, sym=True)
     assert maxerr(s_sym, s_ord) <= 1e-5
+
+
+def test_fused_gather_equals_standalone_gather():
+    """eo == NULL form of the typed-MLP kernel (gather in the prologue) == gather kernel + typed MLP."""
+    from groupnet_amd import ops
+    torch.manual_seed(17)
+    pair, hyper = build_modules(1)
+    pair.to(dev())
+    hyper.to(dev())
+    B, N = 37, 11
+    h = torch.randn(B, N, 64, device=dev())
+    corr = ops.affinity(h)
+    cases = []
+    for s in (3, 11):
+        (H,) = ops.topk_incidence(corr, [s])
+        cases.append((hyper, H, False))
+    Hd = torch.randint(0, 3, (B, 7, N), device=dev()).float()   # dense rows with weight-2 entries
+    cases.append((hyper, Hd, False))
+    cases += [(pair, None, False), (pair, None, True)]
+    items_a, items_b = [], []
+    for mod, H, sym in cases:
+        K = mod.edge_types
+        agg = mod.edge_aggregation_list[0]
+        eo = ops.agg_gather(h, H, sym)
+        ef = torch.rand(B, eo.shape[1], K, device=dev())
+        items_a.append((eo, ef, agg._packed(), K))
+        items_b.append((ops.GatherSpec(h, H, sym), ef, agg._packed(), K))
+    fa = ops.agg_mlp_grouped(items_a)
+    fb = ops.agg_mlp_grouped(items_b)
+    for a, b in zip(fa, fb):
+        assert torch.equal(a, b)
+
+
+def test_fused_scatter_equals_standalone_scatter():
+    """x == NULL form of the 128-wide MLP kernel (scatter in the prologue) == scatter kernel + MLP,
+    in the split (few row blocks) and the whole (many row blocks) form of the kernel."""
+    from groupnet_amd import ops
+    torch.manual_seed(23)
+    pair, hyper = build_modules(1)
+    pair.to(dev())
+    hyper.to(dev())
+    for B in (9, 1500):     # 4 / 516 row blocks: split and whole kernel
+        N = 11
+        h = torch.randn(B, N, 64, device=dev())
+        corr = ops.affinity(h)
+        (H3,) = ops.topk_incidence(corr, [3])
+        (H11,) = ops.topk_incidence(corr, [11])
+        cases = [(hyper, H3, False), (hyper, H11, False), (pair, None, True), (pair, None, False)]
+        a_items, b_items = [], []
+        for mod, H, sym in cases:
+            E = ops._edge_count(H, B, N, sym)
+            feat = torch.randn(B, E, 64, device=dev())
+            pk = mod._packed_mlp2(mod.nmp_mlp_end)
+            a_items.append((ops.agg_scatter(feat, H, h, sym=sym), pk, None))
+            b_items.append((ops.ScatterSpec(feat, H, h, sym), pk, None))
+        ya = ops.mlp2_grouped(a_items)
+        yb = ops.mlp2_grouped(b_items)
+        for a, b in zip(ya, yb):
+            assert maxerr(a, b) <= 1e-6
