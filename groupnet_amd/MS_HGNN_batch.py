@@ -203,10 +203,17 @@ class edge_aggregation(nn.Module):
             with torch.no_grad():
                 l0 = [m.layers[0] for m in self.agg_mlp]
                 l1 = [m.layers[1] for m in self.agg_mlp]
+                # pairwise form: layer 1 of all types as one (K*128 x 64) matrix applied per node (half the
+                # bias rides with each of the two nodes of a pair); layer 2 re-ordered hidden-tile-major
+                w2t = [ops.pack_linear(l.weight.detach().contiguous()).view(2, 4, 4, 256).permute(1, 0, 2, 3).reshape(-1)
+                       for l in l1]
                 self._pk = dict(
                     W=ops.pack_stream([w for a, b in zip(l0, l1) for w in (a.weight, b.weight)]),
                     b1=torch.stack([l.bias.detach() for l in l0]).contiguous(),
-                    b2=torch.stack([l.bias.detach() for l in l1]).contiguous())
+                    b2=torch.stack([l.bias.detach() for l in l1]).contiguous(),
+                    W1cat=ops.pack_linear(torch.cat([l.weight.detach() for l in l0], 0).contiguous()),
+                    b1half=(torch.cat([l.bias.detach() for l in l0]) * 0.5).contiguous(),
+                    W2t=torch.cat(w2t).contiguous())
             self._pk_key = key
         return self._pk
 
@@ -352,12 +359,19 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
 
     def edge2node(edge_feats: Sequence[Tensor], oris: Sequence[Tensor], idx: int) -> List[Tensor]:
         aggs = [m.edge_aggregation_list[idx] for m in mods]
-        if N <= _FUSED_GATHER_MAX_N:
-            # eo = H @ ori is formed inside the typed-MLP kernel (it never exists in HBM)
-            eos = [ops.GatherSpec(o, H, sy) for o, H, sy in zip(oris, Hs, syms)]
-        else:
-            eos = ops.agg_gather_grouped(list(zip(oris, Hs, syms)))
-        feats = ops.agg_mlp_grouped([(eo, ef, a._packed(), a.edge_types) for eo, ef, a in zip(eos, edge_feats, aggs)])
+        items = []
+        for i in range(n):
+            pk, K = aggs[i]._packed(), aggs[i].edge_types
+            if syms[i]:
+                # pairwise: eo = ori_i + ori_j makes the typed MLP's first layer linear in the two nodes, so
+                # it runs once per node (N rows instead of N(N+1)/2 pairs); the pair form does the rest
+                src = ops.PairSpec(ops.node_linear(oris[i], pk["W1cat"], pk["b1half"], K * 128))
+            elif N <= _FUSED_GATHER_MAX_N:
+                src = ops.GatherSpec(oris[i], Hs[i], False)   # eo = H @ ori formed inside the kernel
+            else:
+                src = ops.agg_gather(oris[i], Hs[i])
+            items.append((src, edge_feats[i], pk, K))
+        feats = ops.agg_mlp_grouped(items)
         if N <= _FUSED_GATHER_MAX_N:
             # cat(H^T feat, ori) / N is formed inside the MLP kernel that consumes it
             return [ops.ScatterSpec(f, H, o, sy) for f, H, o, sy in zip(feats, Hs, oris, syms)]

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 8
+ABI_VERSION = 10
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -44,7 +44,7 @@ class GatherGroup(ctypes.Structure):    # gn_gather_group_t
 
 class AggGroup(ctypes.Structure):       # gn_agg_group_t
     _fields_ = [("eo", _P), ("edge_feat", _P), ("W", _P), ("b1", _P), ("b2", _P), ("feat", _P), ("rows", _I),
-                ("K", _I), ("ori", _P), ("H", _P), ("E", _I), ("N", _I), ("sym", _I)]
+                ("K", _I), ("ori", _P), ("H", _P), ("E", _I), ("N", _I), ("sym", _I), ("A", _P)]
 
 
 class ScatterGroup(ctypes.Structure):   # gn_scatter_group_t
@@ -77,6 +77,7 @@ SIGNATURES = {
     "gn_edge_mlp_gumbel_f32": (_I, [ctypes.POINTER(EdgeGroup), _I, _F, _U64, _P, _P]),
     "gn_agg_gather_f32": (_I, [ctypes.POINTER(GatherGroup), _I, _I, _I, _P]),
     "gn_agg_mlp_f32": (_I, [ctypes.POINTER(AggGroup), _I, _P]),
+    "gn_node_linear_f32": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "gn_agg_scatter_f32": (_I, [ctypes.POINTER(ScatterGroup), _I, _I, _I, _F, _P]),
     "gn_mlp2_f32": (_I, [ctypes.POINTER(Mlp2Group), _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "gn_philox_uniform_f32": (_I, [_P, _SZ, _U64, _U64, _P, _P]),

@@ -578,7 +578,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) 
 
 }  // namespace
 
-extern "C" int gn_abi_version(void) { return 8; }
+extern "C" int gn_abi_version(void) { return 10; }
 
 extern "C" const char* gn_strerror(int code) {
   switch (code) {

@@ -357,6 +357,52 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge
   }
 }
 
+// ---- A5, pairwise graph: layer 1 per node, layer 2 per unordered pair -------------------------------
+// y = W x + bias for 64-wide x and dout = 32*OT outputs, 4 waves per row block, wave w taking output
+// tiles [w*OT/4, (w+1)*OT/4): the per-node half of the typed MLP's first layer for all K types at once.
+__global__ __launch_bounds__(256) void node_linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          int rows, int OT) {
+  const int wave = wave_id();
+  const RowBlock rb = row_block(rows, blockIdx.x);
+  const int lane = rb.lane, h = rb.h;
+  const int per = OT >> 2, o0 = wave * per;
+  const f32x4* Wl = reinterpret_cast<const f32x4*>(W) + lane + (size_t)o0 * 8 * kStep;
+  WRing ring;
+  ring_prime(ring, Wl);
+  f32x16 in[2];
+  load_rows<2>(x, GN_FEAT, rb.row_ld, h, in);
+  f32x16 bnext = load_bias_tile(bias + 32 * o0, h);
+  const int ld = 32 * OT;
+#pragma unroll 1
+  for (int o = 0; o < per; ++o) {
+    const bool tail = o == per - 1;
+    f32x16 acc = bnext;
+    bnext = load_bias_tile(bias + 32 * (o0 + (tail ? o : o + 1)), h);
+    const f32x4* cur = Wl + (size_t)o * 8 * kStep;
+    mma_tile<2>(cur, tail ? cur : cur + 8 * kStep, ring, in, acc);
+    if (rb.live) {
+      float* p = y + (size_t)rb.row * ld + 32 * (o0 + o) + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(p + 8 * q) = v;
+      }
+    }
+  }
+}
+
+// The 16 pre-activation values lane (j,h) needs of hidden tile t of type k for ONE node: A row + offset.
+struct PreTile {
+  f32x4 v[4];
+};
+__device__ __forceinline__ PreTile load_pre(const float* __restrict__ arow, int h) {
+  PreTile p;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p.v[q] = *reinterpret_cast<const f32x4*>(arow + 8 * q + 4 * h);
+  return p;
+}
+
 // ---- A5 typed MLP: feat = sum_k ef[:,k] * (W2k relu(W1k eo + b1k) + b2k) --------------------------
 // W = for each type k: [W1k (128x64) | W2k (64x128)] packed (64 steps per type); b1 (K,128); b2 (K,64).
 // Work shape, chosen per group by the launcher (block-uniform): `wpr` waves share one 32-row block,
@@ -438,11 +484,7 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
   if (wpr == 1 && !any_rows) return;
   const RowBlock rb = row_block(rows, any_rows ? blk : 0);
   const int lane = rb.lane, h = rb.h;
-  f32x16 in[2], hid[4], out[2];
-  if (G.eo != nullptr)
-    load_rows<2>(G.eo, GN_FEAT, rb.row_ld, h, in);
-  else
-    gather_rows(G, rb.row_ld, h, in);
+  f32x16 out[2];
 #pragma unroll
   for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -453,7 +495,70 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
   const float* b2 = G.b2;
 
   int k = sub;
-  if (k < K && any_rows) {
+  if (G.A != nullptr) {
+    // ---- pair form: the first layer was applied per node (A = W1 ori + b1/2 for every type) ----------
+    // W = per type 4 hidden tiles x (2 output tiles x 4 steps), consumed strictly in order: 8 steps
+    // (one ring turn) per hidden tile.
+    if (k < K && any_rows) {
+      const int N = G.N, P = G.E;
+      int i, j;
+      {
+        const int b = rb.row_ld / P, p = rb.row_ld - b * P;
+        gn_pair_decode(p, N, i, j);
+        i += b * N;
+        j += b * N;
+      }
+      const size_t ldA = (size_t)K * 128;
+      const float* Ai = G.A + (size_t)i * ldA;
+      const float* Aj = G.A + (size_t)j * ldA;
+      WRing ring;
+      ring_prime(ring, Wl + (size_t)k * 32 * kStep);
+      PreTile pa = load_pre(Ai + k * 128, h), pb = load_pre(Aj + k * 128, h);
+      float efk = efrow[k];
+      float b2f0 = h == 0 ? b2[k * 64 + (lane & 31)] : 0.f;
+      float b2f1 = h == 0 ? b2[k * 64 + 32 + (lane & 31)] : 0.f;
+#pragma unroll 1
+      while (k < K) {
+        const int kn = k + wpr;
+        const int kc = kn < K ? kn : k;
+        const f32x4* base = Wl + (size_t)k * 32 * kStep;
+        const f32x4* base_next = Wl + (size_t)kc * 32 * kStep;
+        const float efk_next = efrow[kc];
+        const float b2n0 = h == 0 ? b2[kc * 64 + (lane & 31)] : 0.f;
+        const float b2n1 = h == 0 ? b2[kc * 64 + 32 + (lane & 31)] : 0.f;
+        const float efb = h == 0 ? efk : 0.f;
+        out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f0, efb, out[0], 0, 0, 0);
+        out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f1, efb, out[1], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          // hidden tile t of this type from the two nodes' pre-activations (b1k/2 rides in each of them)
+          f32x16 hid1[1];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx)
+              hid1[0][4 * q + cidx] = fmaxf(pa.v[q][cidx] + pb.v[q][cidx], 0.f) * efk;
+          // fetch the next tile's pre-activations (next type's tile 0 after t == 3) under this tile's MFMAs
+          const int off = t < 3 ? k * 128 + 32 * (t + 1) : kc * 128;
+          pa = load_pre(Ai + off, h);
+          pb = load_pre(Aj + off, h);
+          const f32x4* cur = base + t * 8 * kStep;
+          const f32x4* nxt = t < 3 ? cur + 8 * kStep : base_next;
+          mma_tile<1, 0, NoSide, 4>(cur, cur + 4 * kStep, ring, hid1, out[0], NoSide(), nxt);
+          mma_tile<1, 4>(cur + 4 * kStep, nxt, ring, hid1, out[1]);
+        }
+        efk = efk_next;
+        b2f0 = b2n0;
+        b2f1 = b2n1;
+        k = kn;
+      }
+    }
+  } else if (k < K && any_rows) {
+    f32x16 in[2], hid[4];
+    if (G.eo != nullptr)
+      load_rows<2>(G.eo, GN_FEAT, rb.row_ld, h, in);
+    else
+      gather_rows(G, rb.row_ld, h, in);
     WRing ring;
     ring_prime(ring, Wl + (size_t)k * kTypeSteps * kStep);
     f32x16 bnext = load_bias_tile(b1 + k * 128, h);
@@ -840,7 +945,10 @@ extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_str
   int wg = 0;
   for (int g = 0; g < n_groups; ++g) {
     const gn_agg_group_t& G = groups[g];
-    if (G.eo != nullptr) {
+    if (G.A != nullptr) {
+      GN_CHECK(need(G.A, true));
+      if (G.N <= 0 || G.E != gn_pair_count(G.N) || G.rows % G.E != 0) return GN_ERR_SHAPE;
+    } else if (G.eo != nullptr) {
       GN_CHECK(need(G.eo, true));
     } else {
       GN_CHECK(need(G.ori, true));
@@ -849,7 +957,7 @@ extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_str
       if (G.H != nullptr && G.sym) return GN_ERR_SHAPE;
     }
     GN_CHECK(need(G.W, true));
-    GN_CHECK(need(G.b1, true));
+    if (G.A == nullptr) GN_CHECK(need(G.b1, true));
     GN_CHECK(need(G.feat, true));
     GN_CHECK(need(G.edge_feat, false));
     GN_CHECK(need(G.b2, false));
@@ -869,6 +977,16 @@ extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_str
   }
   T.first_wg[n_groups] = wg;
   hipLaunchKernelGGL(agg_mlp_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, T);
+  return gn_check_launch();
+}
+
+extern "C" int gn_node_linear_f32(const float* x, const float* W, const float* bias, float* y, int rows, int dout,
+                                  gn_stream_t stream) {
+  const void* ptrs[] = {x, W, bias, y};
+  for (const void* p : ptrs) GN_CHECK(need(p, true));
+  if (rows <= 0 || dout <= 0 || dout % 128 != 0) return GN_ERR_SHAPE;
+  hipLaunchKernelGGL(node_linear_kernel, dim3((rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, W, bias, y, rows,
+                     dout / 32);
   return gn_check_launch();
 }
 

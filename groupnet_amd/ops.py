@@ -328,37 +328,57 @@ class GatherSpec:
         self.ori, self.H, self.sym = ori, H, bool(sym)
 
 
+class PairSpec:
+    """Pair form of the typed MLP for the pairwise graph: A (B,N,K*128) = node_linear(ori) holds the first
+    layer per node; rows are the N(N+1)/2 unordered pairs.  Uses pk["W2t"] instead of pk["W"]."""
+    __slots__ = ("A",)
+
+    def __init__(self, A: Tensor):
+        self.A = A
+
+
 def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[Tensor]:
-    """items = [(eo (B,E,64) or GatherSpec, edge_feat (B,E,K), pk{"W","b1","b2"}, K)] -> [feat (B,E,64)]."""
+    """items = [(eo (B,E,64) | GatherSpec | PairSpec, edge_feat (B,E,K), pk{"W","b1","b2"[,"W2t"]}, K)]
+    -> [feat (B,E,64)]."""
     _groups(len(items))
     arr = (_lib.AggGroup * len(items))()
     outs = []
     flops = 0
     dev0 = None
     for g, (eo, edge_feat, pk, K) in enumerate(items):
-        if isinstance(eo, GatherSpec):
+        wkey = "W"
+        if isinstance(eo, PairSpec):
+            A = eo.A
+            _req(A, "A", (None, None, K * 128))
+            B, N = A.shape[0], A.shape[1]
+            E = pair_count(N)
+            _same_device(A, edge_feat)
+            like, eo_ptr, wkey = A, 0, "W2t"
+            extra = (0, 0, E, N, 1, A.data_ptr())
+        elif isinstance(eo, GatherSpec):
             ori, H = eo.ori, eo.H
             _req(ori, "ori", (None, None, FEAT))
             B, N, _ = ori.shape
             E = _edge_count(H, B, N, eo.sym)
             _same_device(ori, H, edge_feat)
             like, eo_ptr = ori, 0
-            extra = (ori.data_ptr(), 0 if H is None else H.data_ptr(), E, N, int(eo.sym))
+            extra = (ori.data_ptr(), 0 if H is None else H.data_ptr(), E, N, int(eo.sym), 0)
         else:
             _req(eo, "eo", (None, None, FEAT))
             B, E, _ = eo.shape
             _same_device(eo, edge_feat)
             like, eo_ptr = eo, eo.data_ptr()
-            extra = (0, 0, 0, 0, 0)
+            extra = (0, 0, 0, 0, 0, 0)
         dev0 = dev0 or like.device
         if like.device != dev0:
             raise ValueError("grouped launch: every group must be on the same device")
         _req(edge_feat, "edge_feat", (B, E, K))
         feat = torch.empty((B, E, FEAT), dtype=like.dtype, device=like.device)
-        arr[g] = _lib.AggGroup(eo_ptr, edge_feat.data_ptr(), pk["W"].data_ptr(), pk["b1"].data_ptr(),
+        arr[g] = _lib.AggGroup(eo_ptr, edge_feat.data_ptr(), pk[wkey].data_ptr(), pk["b1"].data_ptr(),
                                pk["b2"].data_ptr(), feat.data_ptr(), B * E, K, *extra)
         outs.append(feat)
-        flops += B * E * K * (2 * 64 * 128 + 2 * 128 * 64 + 2 * 64)
+        # executed FLOPs: both layers, or the second layer only in the pair form
+        flops += B * E * K * ((2 * 128 * 64 + 2 * 64) + (0 if wkey == "W2t" else 2 * 64 * 128))
     probe = launch_probe
     with torch.cuda.device(dev0):
         if probe is not None:
@@ -371,6 +391,19 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
 
 def agg_mlp(eo: Tensor, edge_feat: Tensor, pk: dict, K: int) -> Tensor:
     return agg_mlp_grouped([(eo, edge_feat, pk, K)])[0]
+
+
+def node_linear(x: Tensor, W: Tensor, bias: Tensor, dout: int) -> Tensor:
+    """y = W x + bias for x (..., 64): W = packed (dout x 64) image, dout a multiple of 128."""
+    _req(x, "x")
+    if x.shape[-1] != FEAT:
+        raise ValueError("x: last dim must be 64")
+    rows = x.numel() // FEAT
+    y = torch.empty(tuple(x.shape[:-1]) + (dout,), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(load().gn_node_linear_f32(_ptr(x), _ptr(W), _ptr(bias), _ptr(y), rows, dout, stream_handle()),
+              "gn_node_linear_f32")
+    return y
 
 
 def agg_scatter_grouped(items: Sequence[tuple], divisor: Optional[float] = None) -> List[Tensor]:

@@ -192,7 +192,11 @@ int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, int B, int 
  * Fused gather (eo == NULL): the kernel forms its input rows itself from ori (B,N,64) exactly as
  * gn_agg_gather_f32 would — row r = b*E + e is sum_n H[b,e,n] ori[b,n] (H (B,E,N)), or for the
  * pairwise graph (H == NULL) ori_i + ori_j with (i,j) the ordered edge (E = N*N) or the unordered
- * pair (sym = 1, E = N(N+1)/2) — so eo never exists in HBM.  rows must equal B*E. */
+ * pair (sym = 1, E = N(N+1)/2) — so eo never exists in HBM.  rows must equal B*E.
+ * Pair form (A != NULL; pairwise graph, symmetric rows, E = N(N+1)/2): A (B*N, K*128) holds the
+ * per-node first layer W1k ori + b1k/2 (gn_node_linear_f32); row p = (i <= j) computes
+ * sum_k edge_feat[p,k] * (W2k relu(A[i,k] + A[j,k]) + b2k).  W then is, per type, the packed (64 x 128)
+ * image re-ordered hidden-tile-major ((t, o) instead of (o, t)); b1 is unused. */
 typedef struct {
   const float* eo;
   const float* edge_feat;
@@ -207,8 +211,19 @@ typedef struct {
   int E;
   int N;
   int sym;
+  const float* A;
 } gn_agg_group_t;
 int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream);
+
+/* ---- A5, pairwise graph, layer 1 hoisted to the nodes -----------------------------------------
+ * For the pairwise graph the typed MLP's input row is eo = ori_i + ori_j, so its first layer is
+ * linear in the two nodes: W1k eo + b1k = (W1k ori_i + b1k/2) + (W1k ori_j + b1k/2).  The first layer
+ * therefore runs once per NODE (N rows per scene instead of N(N+1)/2 pairs):
+ *   y = W x + bias, x (rows,64) -> y (rows,dout), dout a multiple of 128 (W = packed (dout x 64)
+ *   image; used with W = [W1_0; ...; W1_{K-1}], bias = b1/2 to produce A (B*N, K*128)); the pair form
+ *   of gn_agg_mlp_f32 (field A) then applies relu and the second layer per unordered pair. */
+int gn_node_linear_f32(const float* x, const float* W, const float* bias, float* y, int rows, int dout,
+                       gn_stream_t stream);
 
 /* scatter: out = cat(H^T feat, ori) / divisor     (MS_HGNN_batch.py:267; divisor = N gives the
  * division of edge2node :120,355, divisor = 1 the bare edge_aggregation.forward).

@@ -561,3 +561,27 @@ def test_fused_scatter_equals_standalone_scatter():
         yb = ops.mlp2_grouped(b_items)
         for a, b in zip(ya, yb):
             assert maxerr(a, b) <= 1e-6
+
+
+@pytest.mark.parametrize("B,N", [(37, 11), (3, 50), (5, 1), (700, 4)])
+def test_pairwise_node_level_first_layer_equals_typed_mlp(B, N):
+    """gn_node_linear_f32 + the pair form of gn_agg_mlp_f32 == gather + typed MLP on pair rows."""
+    from groupnet_amd import ops
+    torch.manual_seed(41 + N)
+    pair, _ = build_modules(1)
+    pair.to(dev())
+    agg = pair.edge_aggregation_list[0]
+    K = pair.edge_types
+    pk = agg._packed()
+    h = torch.randn(B, N, 64, device=dev())
+    P = ops.pair_count(N)
+    ef = torch.rand(B, P, K, device=dev())
+    want = ops.agg_mlp(ops.agg_gather(h, None, sym=True), ef, pk, K)
+    A = ops.node_linear(h, pk["W1cat"], pk["b1half"], K * 128)
+    # A == W1 ori + b1/2 for every type
+    W1 = torch.cat([m.layers[0].weight for m in agg.agg_mlp], 0)
+    b1 = torch.cat([m.layers[0].bias for m in agg.agg_mlp], 0)
+    assert maxerr(A, (h @ W1.t() + 0.5 * b1).detach()) <= 1e-5
+    (got,) = ops.agg_mlp_grouped([(ops.PairSpec(A), ef, pk, K)])
+    assert got.shape == (B, P, 64)
+    assert maxerr(got, want) <= 1e-5
