@@ -57,24 +57,45 @@ def agg_hbm_bytes(B, N, E):
 
 
 class Probe:
-    """Brackets every launch of one named kernel with HIP events on the stream it is launched on."""
+    """Brackets every launch of the matrix-core kernels with HIP events on the stream it is launched on."""
 
-    def __init__(self, name):
-        self.name = name
-        self.pairs, self._open = [], None
+    def __init__(self):
+        self.pairs, self._open = {}, {}
 
     def __call__(self, name, flops, before):
-        if name != self.name:
-            return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
         if before:
-            self._open = (ev, flops)
+            self._open[name] = ev
         else:
-            self.pairs.append((self._open[0], ev, self._open[1]))
+            self.pairs.setdefault(name, []).append((self._open.pop(name), ev, flops))
 
-    def mean_ms(self):
-        return statistics.fmean(a.elapsed_time(b) for a, b, _ in self.pairs)
+    def summary(self, overhead_ms):
+        out = {}
+        for name, pr in self.pairs.items():
+            ms = max(statistics.fmean(a.elapsed_time(b) for a, b, _ in pr) - overhead_ms, 1e-6)
+            out[name] = (ms, pr[0][2], len(pr))
+        return out
+
+
+def pmc_traffic(kernel_prefixes):
+    """HBM bytes per launch from the committed PMC passes (profiles/*pmc_traffic.json), or None.
+    PMC counters cannot be read from inside the process; the file says how they were collected."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+        tot = 0
+        for pre in kernel_prefixes:
+            hit = [v for k, v in ks.items() if k.startswith(pre)]
+            if not hit:
+                return None
+            tot += hit[0]["hbm_bytes"]
+        return tot
+    except Exception:
+        return None
 
 
 def empty_bracket_ms(n=50):
@@ -221,10 +242,10 @@ def main():
             elapsed = float(t.item())
 
         # ---- roofline leg: instrumented eager pass over the same K steps (rank 0) -------------------
-        roof = agg = None
+        roof = agg = mfma_kernels = None
         if rank == 0:
             G.set_noise_mode("device", seed=99)
-            probe = Probe("agg_mlp")
+            probe = Probe()
             ops.launch_probe = probe
             torch.cuda.synchronize()
             for _ in range(min(args.steps, 50)):
@@ -233,13 +254,19 @@ def main():
             ops.launch_probe = None
             torch.cuda.synchronize()
             overhead = empty_bracket_ms()
-            ms = max(probe.mean_ms() - overhead, 1e-6)
-            fl = probe.pairs[0][2]
+            summ = probe.summary(overhead)
+            mfma_kernels = {k: dict(avg_launch_us=round(ms * 1e3, 2), flops_per_launch=fl,
+                                    achieved_tflops=round(fl / (ms * 1e-3) / 1e12, 2),
+                                    frac=round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4))
+                            for k, (ms, fl, n) in summ.items()}
+            dom = max(summ, key=lambda k: summ[k][0])       # the kernel with the largest launch time
+            ms, fl, nl = summ[dom]
             ach = fl / (ms * 1e-3) / 1e12
-            roof = dict(kernel="agg_mlp_kernel (typed aggregation MLP, one grouped launch: pairwise + 3 hyper modules)",
+            roof = dict(kernel=dom + (" (typed aggregation MLP: pair form of the pairwise module + 3 hyper modules, "
+                                      "one grouped launch)" if dom == "agg_mlp_kernel" else ""),
                         bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
-                        avg_launch_us=round(ms * 1e3, 2), flops_per_launch=fl, launches_timed=len(probe.pairs),
+                        frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=pmc_traffic([dom]),
+                        avg_launch_us=round(ms * 1e3, 2), flops_per_launch=fl, launches_timed=nl,
                         event_pair_overhead_us=round(overhead * 1e3, 2),
                         measured="single-stream instrumented pass (in the timed region steps overlap across streams, "
                                  "which stretches every kernel; profiles/ holds both views)")
@@ -255,7 +282,8 @@ def main():
             gbs = by / ((t_g + t_s) * 1e-3) / 1e9
             agg = dict(kernel="agg_gather_kernel + agg_scatter_kernel (hyper, E=N=11, B=4096)", bound="hbm",
                        achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
-                       traffic=None, gather_us=round(t_g * 1e3, 2), scatter_us=round(t_s * 1e3, 2),
+                       traffic=pmc_traffic(["agg_gather_kernel", "agg_scatter_kernel"]),
+                       gather_us=round(t_g * 1e3, 2), scatter_us=round(t_s * 1e3, 2),
                        bytes_per_launch_pair=by)
             G.set_noise_mode("host")
 
@@ -280,7 +308,7 @@ def main():
                                    + (", + all-gather of (B,N,320) embeddings over RCCL" if world > 1 else ""),
                        "global_batch": B_total, "agents": N, "scales": SCALES,
                        "parallelism": f"batch-sharded x{world}"},
-            "roofline": roof, "agg_hbm": agg, "cpu_baseline": cpu,
+            "roofline": roof, "agg_hbm": agg, "mfma_kernels": mfma_kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

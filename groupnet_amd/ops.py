@@ -45,6 +45,29 @@ def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
     return _P(0 if t is None else t.data_ptr())
 
 
+# ---- optional instrumentation ----------------------------------------------------------------------
+# bench.py brackets the launches of the matrix-core kernels with HIP events on the stream they are
+# launched on (the roofline leg of the bench contract).  `launch_probe(name, flops, before)` is None in
+# normal use and costs one comparison per launch.
+launch_probe = None
+
+
+class _Probed:
+    __slots__ = ("name", "flops", "probe")
+
+    def __init__(self, name: str, flops: int):
+        self.name, self.flops, self.probe = name, flops, launch_probe
+
+    def __enter__(self):
+        if self.probe is not None:
+            self.probe(self.name, self.flops, True)
+
+    def __exit__(self, *exc):
+        if self.probe is not None:
+            self.probe(self.name, self.flops, False)
+        return False
+
+
 # ---- A0 / A1 -----------------------------------------------------------------------------------
 def affinity(f: Tensor) -> Tensor:
     """corr = normalize(f) @ normalize(f)^T   (model/GroupNet_nba.py:284-286)."""
@@ -173,7 +196,8 @@ def node_mlp_grouped(items: Sequence[Tuple[Tensor, dict]]) -> List[Tuple[Tensor,
         xp, pq = torch.empty_like(x), torch.empty_like(x)
         arr[g] = _lib.NodeGroup(x.data_ptr(), pk["W"].data_ptr(), pk["bias"].data_ptr(), xp.data_ptr(), pq.data_ptr())
         outs.append((xp, pq))
-    with torch.cuda.device(x0.device):
+    flops = len(items) * rows * 2 * (64 * 256 + 256 * 64 + 64 * 64)
+    with torch.cuda.device(x0.device), _Probed("node_mlp_kernel", flops):
         check(load().gn_node_mlp_f32(arr, len(items), rows, stream_handle()), "gn_node_mlp_f32")
     return outs
 
@@ -273,7 +297,8 @@ def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5) -> List[Tu
         arr[g] = _lib.EdgeGroup(edges.data_ptr(), u_ptr, pk["W"].data_ptr(), pk["bias"].data_ptr(),
                                 edge_feat.data_ptr(), 0 if dist is None else dist.data_ptr(), off, B * E, K, sym_N)
         outs.append((edge_feat, dist))
-    with torch.cuda.device(e0.device):
+    flops = sum(int(a.rows) for a in arr) * 2 * (64 * 128 + 128 * 64 + 64 * 256 + 256 * 32)
+    with torch.cuda.device(e0.device), _Probed("edge_mlp_gumbel_kernel", flops):
         check(load().gn_edge_mlp_gumbel_f32(arr, len(items), float(tau), seed or 0, _ptr(ctr), stream_handle()),
               "gn_edge_mlp_gumbel_f32")
     return outs
@@ -379,13 +404,8 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
         outs.append(feat)
         # executed FLOPs: both layers, or the second layer only in the pair form
         flops += B * E * K * ((2 * 128 * 64 + 2 * 64) + (0 if wkey == "W2t" else 2 * 64 * 128))
-    probe = launch_probe
-    with torch.cuda.device(dev0):
-        if probe is not None:
-            probe("agg_mlp", flops, True)
+    with torch.cuda.device(dev0), _Probed("agg_mlp_kernel", flops):
         check(load().gn_agg_mlp_f32(arr, len(items), stream_handle()), "gn_agg_mlp_f32")
-        if probe is not None:
-            probe("agg_mlp", flops, False)
     return outs
 
 
@@ -400,7 +420,7 @@ def node_linear(x: Tensor, W: Tensor, bias: Tensor, dout: int) -> Tensor:
         raise ValueError("x: last dim must be 64")
     rows = x.numel() // FEAT
     y = torch.empty(tuple(x.shape[:-1]) + (dout,), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _Probed("node_linear_kernel", rows * 2 * 64 * dout):
         check(load().gn_node_linear_f32(_ptr(x), _ptr(W), _ptr(bias), _ptr(y), rows, dout, stream_handle()),
               "gn_node_linear_f32")
     return y
@@ -508,7 +528,8 @@ def mlp2_grouped(items: Sequence[Tuple[object, dict, Optional[Tensor]]]) -> List
     rows = 1
     for d_ in shape0:
         rows *= int(d_)
-    with torch.cuda.device(dev0):
+    flops = len(items) * rows * 2 * (din * dh + dh * (((dout + 31) // 32) * 32))
+    with torch.cuda.device(dev0), _Probed("mlp2_kernel", flops):
         check(load().gn_mlp2_f32(arr, len(items), rows, din, dh, dout, ld0, N, divisor, stream_handle()),
               "gn_mlp2_f32")
     return outs
@@ -542,7 +563,3 @@ def counter_add(counter: Tensor, add: int) -> None:
         check(load().gn_counter_add_u64(_ptr(counter), int(add), stream_handle()), "gn_counter_add_u64")
 
 
-# ---- optional instrumentation ----------------------------------------------------------------------
-# bench.py brackets ONE named launch with HIP events on the stream it is launched on (the roofline
-# leg of the bench contract).  `launch_probe` is None in normal use and costs one comparison.
-launch_probe = None

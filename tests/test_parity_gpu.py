@@ -585,3 +585,24 @@ def test_pairwise_node_level_first_layer_equals_typed_mlp(B, N):
     (got,) = ops.agg_mlp_grouped([(ops.PairSpec(A), ef, pk, K)])
     assert got.shape == (B, P, 64)
     assert maxerr(got, want) <= 1e-5
+
+
+def test_hyper_module_large_n_256():
+    """BASELINE config 5 shape (N=256, scales {2,8,32,128}), small B: the hyper module against the
+    oracle (decomposed attention — the reference's (B,E,N,128) tensor would be 8.6 GB per scene for the
+    pairwise module, SURVEY §7, so only the hyper module has an oracle at this N)."""
+    torch.manual_seed(256)
+    _, hyper = build_modules(1)
+    sh = {k: v.detach().clone() for k, v in hyper.state_dict().items()}
+    hyper.to(dev()).eval()
+    B, N = 2, 256
+    h = torch.randn(B, N, 64)
+    corr = O.affinity(h)
+    with torch.no_grad():
+        for s in (2, 8, 32, 128):
+            U = [torch.rand(x) for x in O.noise_shapes(B, N, s, 1)]
+            nf_o, fac_o, H_o = O.ms_hgnn_hyper_forward(sh, h, corr, s, U, 1, decomposed=True)
+            hyper.scale = s
+            nf, fac, H = hyper(h.to(dev()), corr.to(dev()), noise_u=[u.to(dev()) for u in U])
+            assert torch.equal(H.cpu(), H_o)
+            assert maxerr(nf, nf_o) <= TOL and maxerr(fac, fac_o) <= TOL
