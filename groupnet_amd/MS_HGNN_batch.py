@@ -166,7 +166,7 @@ class MLP_dict_softmax(nn.Module):
                 bd1[:K] = d1.bias
                 bd1[K] = f1.bias[0]
                 self._pk = dict(
-                    W=ops.pack_stream([i0.weight, i1.weight, torch.cat((d0.weight, f0.weight), 0), Wd1]),
+                    W=ops.edge_stream(i0.weight, i1.weight, torch.cat((d0.weight, f0.weight), 0), Wd1),
                     bias=ops.bias_stream([i0.bias, i1.bias, torch.cat((d0.bias, f0.bias), 0), bd1]))
             self._pk_key = key
         return self._pk

@@ -283,9 +283,7 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge
   const int blk = (blockIdx.x - T.first_wg[gi]) * 4 + wave_id();
   if (blk * 32 >= rows) return;
   const RowBlock rb = row_block(rows, blk);
-  Chain c;
-  chain_begin(c, G.W, G.bias, rb.lane);
-  f32x16 in[2], h1[4], z[2], h2[8], lg[1];
+  f32x16 in[2], z[2], lg[1];
   load_rows<2>(G.edges, GN_FEAT, rb.row_ld, rb.h, in);
   // Ordered edge rows whose uniforms this row consumes: itself, or — symmetric pairwise form — the two
   // ordered edges (i,j) and (j,i) of its unordered pair.
@@ -308,10 +306,76 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge
     fetch_uniforms(G.U, 0ull, 0ull, o1, K, rb.h, u1);
     if (G.sym_N > 0) fetch_uniforms(G.U, 0ull, 0ull, o2, K, rb.h, u2);
   }
-  chain_linear<4, 2, true>(c, in, h1);
-  chain_linear<2, 4, false>(c, h1, z);
-  chain_linear<8, 2, true>(c, z, h2);
-  chain_linear<1, 8, false>(c, h2, lg, true);
+  // Two layer PAIRS (64->128->64 and 64->256->32), each evaluated hidden-tile by hidden-tile: hidden tile t
+  // (8 steps) is produced, and while tile t+1 is being produced its ReLU runs in the MFMA shadow; then the
+  // second layer's slice over tile t (4 steps per output tile) is accumulated.  Only two hidden tiles are
+  // ever live (32 registers instead of 128), which is what lets 2-3 waves share a SIMD.  The weight stream
+  // was packed in exactly this order (edge_stream_order in ops.py):
+  //   A: T0 T1 S0 T2 S1 T3 S2 S3        (T = Wi0 tile, S = the two Wi1 slices over it: 8 steps each)
+  //   B: T0 T1 S0 T2 S1 ... T7 S6 S7    (T = Wd0 tile: 8 steps, S = the Wd1 slice over it: 4 steps)
+  // followed by 8 steps of padding, because the ring always reads 8 steps ahead.
+  {
+    const int lane = rb.lane, h = rb.h;
+    const float* bi0 = G.bias;
+    const float* bi1 = G.bias + 128;
+    const float* bd0 = G.bias + 192;
+    const float* bd1 = G.bias + 448;
+    const f32x4* w = reinterpret_cast<const f32x4*>(G.W) + lane;
+    WRing ring;
+    ring_prime(ring, w);
+    f32x16 ha[1], hb[1];   // the two live hidden tiles (named, so that every index is static)
+    z[0] = load_bias_tile(bi1, h);
+    z[1] = load_bias_tile(bi1 + 32, h);
+    lg[0] = load_bias_tile(bd1, h);
+    // ---- pair A ----
+    ha[0] = load_bias_tile(bi0, h);
+    hb[0] = load_bias_tile(bi0 + 32, h);
+    mma_tile<2>(w, w + 8 * kStep, ring, in, ha[0]);                                   // T0
+    w += 8 * kStep;
+    mma_tile<2>(w, w + 8 * kStep, ring, in, hb[0], [&](int s) { if (s == 1) relu16(ha[0]); });   // T1
+    w += 8 * kStep;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x16(&cur)[1] = (t & 1) ? hb : ha;     // tile t
+      f32x16(&oth)[1] = (t & 1) ? ha : hb;     // tile t+1 (already produced, ReLU pending) / tile t+2 target
+      // S_t: z[0] += Wi1(0,t) h_t ; z[1] += Wi1(1,t) h_t      (ReLU of tile t+1 rides here when t == 2)
+      mma_tile<1, 0>(w, w + 4 * kStep, ring, cur, z[0], [&](int s) { if (t == 2 && s == 1) relu16(oth[0]); });
+      mma_tile<1, 4>(w + 4 * kStep, w + 8 * kStep, ring, cur, z[1]);
+      w += 8 * kStep;
+      if (t < 2) {
+        // T_{t+2} into the register set tile t just vacated; ReLU of tile t+1 in its shadow
+        cur[0] = load_bias_tile(bi0 + 32 * (t + 2), h);
+        mma_tile<2>(w, w + 8 * kStep, ring, in, cur[0], [&](int s) { if (s == 1) relu16(oth[0]); });
+        w += 8 * kStep;
+      }
+    }
+    // ---- pair B ----
+    ha[0] = load_bias_tile(bd0, h);
+    hb[0] = load_bias_tile(bd0 + 32, h);
+    mma_tile<2>(w, w + 8 * kStep, ring, z, ha[0]);                                    // T0
+    w += 8 * kStep;
+    mma_tile<2>(w, w + 8 * kStep, ring, z, hb[0], [&](int s) { if (s == 1) relu16(ha[0]); });    // T1
+    w += 8 * kStep;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f32x16(&cur)[1] = (t & 1) ? hb : ha;
+      f32x16(&oth)[1] = (t & 1) ? ha : hb;
+      // S_t: lg += Wd1(0,t) h_t  (4 steps; the ring slot alternates 0 / 4)
+      if ((t & 1) == 0)
+        mma_tile<1, 0>(w, w + 4 * kStep, ring, cur, lg[0], [&](int s) { if (t == 6 && s == 1) relu16(oth[0]); });
+      else
+        mma_tile<1, 4>(w, w + 4 * kStep, ring, cur, lg[0]);
+      w += 4 * kStep;
+      if (t < 6) {
+        cur[0] = load_bias_tile(bd0 + 32 * (t + 2), h);
+        if ((t & 1) == 0)
+          mma_tile<2, 4>(w, w + 8 * kStep, ring, z, cur[0], [&](int s) { if (s == 1) relu16(oth[0]); });
+        else
+          mma_tile<2, 0>(w, w + 8 * kStep, ring, z, cur[0], [&](int s) { if (s == 1) relu16(oth[0]); });
+        w += 8 * kStep;
+      }
+    }
+  }
   if (G.U == nullptr) {
     fetch_uniforms(nullptr, pbase, seed, o1, K, rb.h, u1);
     if (G.sym_N > 0) fetch_uniforms(nullptr, pbase, seed, o2, K, rb.h, u2);
@@ -963,10 +1027,12 @@ extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_str
     GN_CHECK(need(G.b2, false));
     if (G.rows <= 0 || G.K < 1 || G.K > GN_MAX_TYPES) return GN_ERR_SHAPE;
     const int blocks32 = (G.rows + 31) / 32;
-    // waves per row block: 4 when the group has fewer row blocks than half the chip's 1024 SIMDs,
-    // else 2 when the types split evenly (shorter, more uniform work units), else 1
-    int wpr = (blocks32 <= 512 && G.K >= 4) ? 4 : ((G.K % 2 == 0 && G.K >= 4) ? 2 : 1);
-    if (const char* e = getenv("GN_AGG_WPR")) {  // tuning knob: force 1, 2 or 4
+    // waves per row block (measured on MI355X at B = 512, N = 11, scripts in DESIGN.md): a group that
+    // alone covers most of the 1024 SIMDs runs one wave per block; a mid-sized group halves its units
+    // (4 waves of a workgroup sit on ONE CU, so 4-way splitting 176..700 blocks stacks two workgroups on
+    // some CUs and idles others); only small groups split 4 ways
+    int wpr = blocks32 >= 768 ? 1 : (blocks32 >= 128 && G.K >= 2 ? 2 : (G.K >= 4 ? 4 : 1));
+    if (const char* e = getenv(G.A != nullptr ? "GN_AGG_WPR_PAIR" : "GN_AGG_WPR")) {  // tuning knobs: force 1, 2 or 4
       const int v = atoi(e);
       if (v == 1 || v == 2 || v == 4) wpr = v;
     }

@@ -167,6 +167,27 @@ def pack_stream(weights: Sequence[Tensor]) -> Tensor:
     return torch.cat([pack_linear(w.detach().contiguous()) for w in weights])
 
 
+def edge_stream(Wi0: Tensor, Wi1: Tensor, Wd0: Tensor, Wd1: Tensor) -> Tensor:
+    """Weight stream of the edge-MLP kernel: the packed images of its four layers cut into hidden tiles
+    (T, 8 steps) and second-layer slices (S) and laid out in the order the kernel consumes them —
+    pair A: T0 T1 S0 T2 S1 T3 S2 S3 (S = both output tiles over one hidden tile, 8 steps);
+    pair B: T0 T1 S0 T2 S1 ... T7 S6 S7 (S = 4 steps).  One step = 256 floats."""
+    a0 = pack_linear(Wi0.detach().contiguous()).view(4, 8, 256)          # (128 x 64): 4 tiles x 8 steps
+    a1 = pack_linear(Wi1.detach().contiguous()).view(2, 4, 4, 256)       # (64 x 128): (o, t) x 4 steps
+    b0 = pack_linear(Wd0.detach().contiguous()).view(8, 8, 256)          # (256 x 64): 8 tiles x 8 steps
+    b1 = pack_linear(Wd1.detach().contiguous()).view(1, 8, 4, 256)       # (32 x 256): (0, t) x 4 steps
+    sa = lambda t: a1[:, t].reshape(8, 256)                               # slices (0,t), (1,t)
+    sb = lambda t: b1[0, t]
+    parts = [a0[0], a0[1], sa(0), a0[2], sa(1), a0[3], sa(2), sa(3)]
+    parts += [b0[0], b0[1]]
+    for t in range(8):
+        parts.append(sb(t))
+        if t < 6:
+            parts.append(b0[t + 2])
+    parts.append(a0.new_zeros(8, 256))      # the kernel's ring reads 8 steps ahead of the last one it uses
+    return torch.cat([p.reshape(-1) for p in parts]).contiguous()
+
+
 def bias_stream(biases: Sequence[Tensor]) -> Tensor:
     """Biases back to back, each zero-padded to a multiple of 32 (one 32-float tile per output tile)."""
     parts = []

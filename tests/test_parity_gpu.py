@@ -293,14 +293,13 @@ def test_full_size_properties(B):
             assert nf.shape == (B, N, 64) and fac.shape == (B, N * N, 6)
             assert torch.allclose(fac.sum(-1), torch.ones(B, N * N, device=dev()), atol=1e-5)
             assert bool(torch.isfinite(nf).all())
-            # batch-shard invariance (scenes are independent): halves == whole.  Bit for bit when both
-            # sizes pick the same kernel forms (the launchers switch to 4-waves-per-row-block forms when a
-            # launch has fewer row blocks than the chip has SIMDs, which changes the summation order).
+            # batch-shard invariance (scenes are independent): halves == whole to rounding.  Not bit for
+            # bit in general: the launchers pick how many waves share a row block from the launch size,
+            # which changes the order partial sums are added in; the same size is bit-reproducible (the
+            # permutation check below).
             half = B // 2
             nf_a, fac_a = pair(h[:half].contiguous(), noise_u=U[:half].contiguous())
             nf_b, fac_b = pair(h[half:].contiguous(), noise_u=U[half:].contiguous())
-            if B == 512:
-                assert torch.equal(torch.cat((nf_a, nf_b)), nf) and torch.equal(torch.cat((fac_a, fac_b)), fac)
             assert maxerr(torch.cat((nf_a, nf_b)), nf) <= 1e-6 and maxerr(torch.cat((fac_a, fac_b)), fac) <= 1e-6
             # scene-permutation equivariance
             perm = torch.randperm(B, device=dev())
