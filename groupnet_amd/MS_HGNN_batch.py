@@ -433,6 +433,9 @@ class MS_HGNN_oridinary(_MessagePassing):
         _check_forward_only(h_states)
         ops._req(h_states, "h_states", (None, None, self.h_dim))
         N = h_states.shape[1]
+        if h_states.shape[0] == 0 or N == 0:      # empty batch: nothing to launch
+            nf = out if out is not None else h_states.new_empty((h_states.shape[0], N, self.bottleneck_dim))
+            return nf, h_states.new_empty((h_states.shape[0], N * N, self.edge_types))
         return self._run(h_states, None, N * N, noise_u, out)
 
 
@@ -478,6 +481,13 @@ class MS_HGNN_hyper(_MessagePassing):
         fused launch (``ops.affinity_topk``) hand it in; by default it is built here from ``corr``."""
         _check_forward_only(h_states, corr)
         ops._req(h_states, "h_states", (None, None, self.h_dim))
+        if h_states.shape[0] == 0:                  # empty batch: nothing to launch
+            B, N = h_states.shape[0], h_states.shape[1]
+            if self.scale > N:
+                raise RuntimeError("selected index k out of range")
+            E = 1 if self.scale == N else N
+            nf = out if out is not None else h_states.new_empty((B, N, self.bottleneck_dim))
+            return nf, h_states.new_empty((B, E, self.edge_types)), h_states.new_empty((B, E, N))
         if H is None:
             H = self.init_adj_attention(h_states, corr, scale_factor=self.scale)
         else:

@@ -605,3 +605,19 @@ def test_hyper_module_large_n_256():
             nf, fac, H = hyper(h.to(dev()), corr.to(dev()), noise_u=[u.to(dev()) for u in U])
             assert torch.equal(H.cpu(), H_o)
             assert maxerr(nf, nf_o) <= TOL and maxerr(fac, fac_o) <= TOL
+
+
+def test_empty_batch_returns_empty_tensors():
+    """B = 0 (the reference's torch ops accept it): same shapes, no launch."""
+    pair, hyper = build_modules(1)
+    pair.to(dev())
+    hyper.to(dev())
+    h = torch.zeros(0, 11, 64, device=dev())
+    with torch.no_grad():
+        nf, fac = pair(h)
+        assert nf.shape == (0, 11, 64) and fac.shape == (0, 121, 6)
+        hyper.scale = 5
+        nf, fac, H = hyper(h, torch.zeros(0, 11, 11, device=dev()))
+        assert nf.shape == (0, 11, 64) and fac.shape == (0, 11, 10) and H.shape == (0, 11, 11)
+        hyper.scale = 11
+        assert hyper(h, torch.zeros(0, 11, 11, device=dev()))[2].shape == (0, 1, 11)
