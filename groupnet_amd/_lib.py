@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -57,7 +57,8 @@ class Mlp2Group(ctypes.Structure):      # gn_mlp2_group_t
 
 
 class BlockExtras(ctypes.Structure):    # gn_block_extras_t
-    _fields_ = [("f_out", _P), ("f_out_ld", _I), ("H_cat", _P), ("counter", _P), ("counter_add", _U64)]
+    _fields_ = [("f_out", _P), ("f_out_ld", _I), ("H_cat", _P), ("counter", _P), ("counter_add", _U64),
+                ("x_raw", _P), ("x_dim", _I), ("M", _P), ("c", _P), ("f_contig", _P)]
 
 
 MAX_GROUPS = 10

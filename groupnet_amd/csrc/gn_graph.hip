@@ -63,9 +63,30 @@ __global__ __launch_bounds__(kBlock) void affinity_topk_kernel(const float* __re
   const float* fb = f + (size_t)b * N * D;
   const int d4 = D >> 2;
   if (ex.counter != nullptr && b == 0 && threadIdx.x == 0) *ex.counter += ex.counter_add;
+  float* xs = cr + N * N;  // N x x_dim raw inputs (embedding form only)
+  if (ex.x_raw != nullptr) {
+    const float* xb = ex.x_raw + (size_t)b * N * ex.x_dim;
+    for (int idx = threadIdx.x; idx < N * ex.x_dim; idx += kBlock) xs[idx] = xb[idx];
+    __syncthreads();
+  }
   for (int idx = threadIdx.x; idx < N * d4; idx += kBlock) {
     const int r = idx / d4, cc = idx - r * d4;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(fb + (size_t)r * D + 4 * cc);
+    f32x4 v;
+    if (ex.x_raw != nullptr) {
+      // f = M x + c[agent slot]: the whole embedding front-end is one affine map in eval mode
+      v = *reinterpret_cast<const f32x4*>(ex.c + (size_t)r * D + 4 * cc);
+      const float* xr = xs + r * ex.x_dim;
+      for (int k = 0; k < ex.x_dim; ++k) {
+        const float xv = xr[k];
+        v[0] = fmaf(ex.M[(size_t)(4 * cc + 0) * ex.x_dim + k], xv, v[0]);
+        v[1] = fmaf(ex.M[(size_t)(4 * cc + 1) * ex.x_dim + k], xv, v[1]);
+        v[2] = fmaf(ex.M[(size_t)(4 * cc + 2) * ex.x_dim + k], xv, v[2]);
+        v[3] = fmaf(ex.M[(size_t)(4 * cc + 3) * ex.x_dim + k], xv, v[3]);
+      }
+      *reinterpret_cast<f32x4*>(ex.f_contig + ((size_t)b * N + r) * D + 4 * cc) = v;
+    } else {
+      v = *reinterpret_cast<const f32x4*>(fb + (size_t)r * D + 4 * cc);
+    }
     *reinterpret_cast<f32x4*>(q + r * ldq + 4 * cc) = v;
     if (ex.f_out != nullptr) *reinterpret_cast<f32x4*>(ex.f_out + ((size_t)b * N + r) * ex.f_out_ld + 4 * cc) = v;
   }
@@ -578,7 +599,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) 
 
 }  // namespace
 
-extern "C" int gn_abi_version(void) { return 10; }
+extern "C" int gn_abi_version(void) { return 11; }
 
 extern "C" const char* gn_strerror(int code) {
   switch (code) {
@@ -634,13 +655,21 @@ extern "C" int gn_topk_incidence_f32(const float* corr, float* const* H_list, co
 
 extern "C" int gn_affinity_topk_f32(const float* f, float* corr, float* const* H_list, const int* k_list, int n_scales,
                                     int B, int N, int D, const gn_block_extras_t* extras, gn_stream_t stream) {
-  GN_REQUIRE_PTR(f);
-  GN_REQUIRE_ALIGNED(f);
+  const bool embed = extras != nullptr && extras->x_raw != nullptr;
+  if (!embed) {
+    GN_REQUIRE_PTR(f);
+    GN_REQUIRE_ALIGNED(f);
+  }
   if (B <= 0 || N <= 0 || D <= 0 || (D & 3) || D > 1024) return GN_ERR_SHAPE;
   ScaleList sl;
   const int rc = fill_scales(sl, H_list, k_list, n_scales, N);
   if (rc != GN_OK) return rc;
-  const size_t fused = (size_t)N * (D + 4 + N) * sizeof(float);
+  size_t fused = (size_t)N * (D + 4 + N) * sizeof(float);
+  if (embed) {
+    if (extras->x_dim <= 0 || !extras->M || !extras->c || !extras->f_contig) return GN_ERR_NULL;
+    if (!gn_aligned16(extras->c) || !gn_aligned16(extras->f_contig)) return GN_ERR_ALIGN;
+    fused += (size_t)N * extras->x_dim * sizeof(float);
+  }
   if (fused > kLdsBudget) return GN_ERR_LDS;
   gn_block_extras_t ex{};
   if (extras != nullptr) {

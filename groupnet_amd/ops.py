@@ -112,14 +112,27 @@ def topk_incidence(corr: Tensor, scales: Sequence[int]) -> List[Tensor]:
     return Hs
 
 
-def affinity_topk(f: Tensor, scales: Sequence[int], want_corr: bool = True, f_out: Optional[Tensor] = None,
-                  want_H_cat: bool = False, counter: Optional[Tensor] = None, counter_add: int = 0
-                  ) -> Tuple[Optional[Tensor], List[Tensor], Optional[Tensor]]:
+def affinity_topk(f: Optional[Tensor], scales: Sequence[int], want_corr: bool = True, f_out: Optional[Tensor] = None,
+                  want_H_cat: bool = False, counter: Optional[Tensor] = None, counter_add: int = 0,
+                  embed: Optional[Tuple[Tensor, Tensor, Tensor]] = None):
     """Fused A0+A1: f -> (corr, [H_s], H_cat) in one launch.
 
     Extras for the multiscale block (no copy kernels after this launch): ``f_out`` — a last-dim slice
     (B, N, D) of a wider contiguous tensor that also receives f; ``want_H_cat`` — also build
-    cat(H_s, dim=1); ``counter``/``counter_add`` — advance the device Philox position."""
+    cat(H_s, dim=1); ``counter``/``counter_add`` — advance the device Philox position.
+    ``embed`` = (x_raw (B,N,xd), M (D,xd), c (N,D)): f itself is computed in the launch as M x + c[n]
+    (pass f=None); a fourth return value then carries f (B,N,D)."""
+    f_contig = None
+    if embed is not None:
+        x_raw, M, c = embed
+        _req(x_raw, "x_raw", (None, None, None))
+        B, N, xd = x_raw.shape
+        _req(M, "M", (None, xd))
+        D = M.shape[0]
+        _req(c, "c", (N, D))
+        _same_device(x_raw, M, c)
+        f_contig = torch.empty((B, N, D), dtype=x_raw.dtype, device=x_raw.device)
+        f = f_contig          # shapes / device for the allocations below; the kernel ignores its contents
     _req(f, "f", (None, None, None))
     B, N, D = f.shape
     corr = torch.empty((B, N, N), dtype=f.dtype, device=f.device) if want_corr else None
@@ -139,9 +152,14 @@ def affinity_topk(f: Tensor, scales: Sequence[int], want_corr: bool = True, f_ou
         if not (counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1):
             raise ValueError("counter: a 1-element int64 GPU tensor")
         ex.counter, ex.counter_add = counter.data_ptr(), int(counter_add) & (2**64 - 1)
+    if embed is not None:
+        ex.x_raw, ex.x_dim, ex.M, ex.c, ex.f_contig = (embed[0].data_ptr(), embed[0].shape[2], embed[1].data_ptr(),
+                                                      embed[2].data_ptr(), f_contig.data_ptr())
     with torch.cuda.device(f.device):
         check(load().gn_affinity_topk_f32(_ptr(f), _ptr(corr), Hl, kl, n, B, N, D, ctypes.byref(ex), stream_handle()),
               "gn_affinity_topk_f32")
+    if embed is not None:
+        return corr, Hs, H_cat, f_contig
     return corr, Hs, H_cat
 
 

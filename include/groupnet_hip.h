@@ -72,13 +72,23 @@ int gn_topk_incidence_f32(const float* corr, float* const* H_list, const int* k_
  *             the concatenated feature tensor);
  *   H_cat   : every H_s is also written into the (B, sum_s E_s, N) concatenation, scale order;
  *   counter : *counter += counter_add by one thread (advances the device Philox position once per
- *             forward, see gn_edge_mlp_gumbel_f32) — ordered before every later launch of the stream. */
+ *             forward, see gn_edge_mlp_gumbel_f32) — ordered before every later launch of the stream;
+ *   x_raw   : the agent embedding itself is computed here: f[b,n] = M x_raw[b,n] + c[n]
+ *             with x_raw (B,N,x_dim), M (D,x_dim), c (N,D) — the embedding front-end of
+ *             PastEncoder.forward (model/GroupNet_nba.py:269-280), which in eval mode is one affine map
+ *             per agent slot; the `f` argument is then ignored and f is ALSO written contiguously to
+ *             f_contig (B,N,D), the h_states input of the modules. */
 typedef struct {
   float* f_out;
   int f_out_ld;
   float* H_cat;
   unsigned long long* counter;
   unsigned long long counter_add;
+  const float* x_raw;
+  int x_dim;
+  const float* M;
+  const float* c;
+  float* f_contig;
 } gn_block_extras_t;
 int gn_affinity_topk_f32(const float* f, float* corr, float* const* H_list, const int* k_list,
                          int n_scales, int B, int N, int D, const gn_block_extras_t* extras,

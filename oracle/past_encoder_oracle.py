@@ -1,0 +1,65 @@
+"""CPU oracle for the PastEncoder front-end.  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: `model/GroupNet_nba.py` cannot be imported in the build container (its line 2 imports
+`tkinter`, `model/utils.py:8` imports `glob2`; neither package exists here and libraries the image lacks
+stay absent), and the reference holds no fixtures for this block.  This file is therefore a restatement
+written from reading the source (each function cites the lines it follows), checked only for internal
+consistency (the composed affine map of the HIP path == this layer-by-layer evaluation).  The
+MS-HGNN modules it calls ARE pinned (oracle/ms_hgnn_oracle.py).
+
+What it restates: `PositionalAgentEncoding` (model/GroupNet_nba.py:156-195) and the embedding lines of
+`PastEncoder.forward` (:266-286) in eval mode (dropout is the identity).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+State = Dict[str, Tensor]
+
+
+def build_pos_enc(max_len: int, d_model: int) -> Tensor:
+    """`PositionalAgentEncoding.build_pos_enc` (model/GroupNet_nba.py:168-174): sin on even, cos on odd
+    feature indices, frequencies 10000^(-2i/d)."""
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def category_onehot(N: int, like: Tensor) -> Tensor:
+    """`PastEncoder.add_category` (model/GroupNet_nba.py:252-264): rows 0..4 -> team A, 5..9 -> team B,
+    row 10 -> ball, hard-coded (so N <= 10 raises IndexError exactly as the reference does)."""
+    category = torch.zeros(N, 3).type_as(like)
+    category[0:5, 0] = 1
+    category[5:10, 1] = 1
+    category[10, 2] = 1
+    return category
+
+
+def embed(state: State, inputs: Tensor, batch_size: int, agent_num: int) -> Tensor:
+    """`PastEncoder.forward` lines 269-280, eval mode: inputs (B*N, T, in_dim) -> ftraj_input (B,N,D)."""
+    D = state["input_fc.weight"].shape[0]
+    T = inputs.shape[1]
+    tf_in = F.linear(inputs, state["input_fc.weight"], state["input_fc.bias"]).view(batch_size * agent_num, T, D)  # :269
+    pe = state["pos_encoder.pe"][0:T, :][None].repeat(batch_size * agent_num, 1, 1)                               # :177-178
+    x = torch.cat([tf_in, pe], dim=-1)                                                                             # :190-191
+    tf_in_pos = F.linear(x, state["pos_encoder.fc.weight"], state["pos_encoder.fc.bias"])                          # :192 (dropout = id)
+    tf_in_pos = tf_in_pos.view(batch_size, agent_num, T, D)                                                        # :273
+    ftraj = F.linear(tf_in_pos.contiguous().view(batch_size, agent_num, T * D),
+                     state["input_fc2.weight"], state["input_fc2.bias"])                                           # :276-277
+    cat = category_onehot(agent_num, ftraj).repeat(batch_size, 1, 1)                                              # :262
+    return F.linear(torch.cat((ftraj, cat), dim=-1), state["input_fc3.weight"], state["input_fc3.bias"])          # :279-280
+
+
+def embed_and_affinity(state: State, inputs: Tensor, batch_size: int, agent_num: int) -> Tuple[Tensor, Tensor]:
+    """Lines 269-286: (ftraj_input, feat_corr)."""
+    f = embed(state, inputs, batch_size, agent_num)
+    q = F.normalize(f, p=2, dim=2)
+    return f, torch.matmul(q, q.permute(0, 2, 1))
