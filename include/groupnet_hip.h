@@ -154,9 +154,12 @@ int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, g
  * Replaces MLP_dict_softmax.forward + gumbel_softmax, MS_HGNN_batch.py:41-53,446-520:
  *   z = MLP_{64->128->64}(edges); logits = MLP_{64->128->K}(z); fac = sigmoid(MLP_{64->128->1}(z));
  *   g = -log(1e-10 - log(U + 1e-10)); dist = softmax((logits + g) / tau); edge_feat = fac * dist.
- * W = packed [init_MLP.0 (128x64) | init_MLP.1 (64x128) | Wd0 (256x64) | Wd1 (32x256)] where
- *   Wd0 = [MLP_distribution.layers.0 ; MLP_factor.layers.0] and Wd1 is the block matrix whose rows
- *   0..K-1 are [MLP_distribution.layers.1, 0] and row K is [0, MLP_factor.layers.1];
+ * W = the packed images of Wi0 = init_MLP.0 (128x64), Wi1 = init_MLP.1 (64x128), Wd0 (256x64) and
+ *   Wd1 (32x256), where Wd0 = [MLP_distribution.layers.0 ; MLP_factor.layers.0] and Wd1 is the block
+ *   matrix whose rows 0..K-1 are [MLP_distribution.layers.1, 0] and row K is [0, MLP_factor.layers.1],
+ *   cut into hidden tiles T (8 steps of 256 floats) and second-layer slices S and ordered as the kernel
+ *   consumes them:  Wi0/Wi1: T0 T1 S0 T2 S1 T3 S2 S3 (S_t = Wi1 tiles (0,t),(1,t): 8 steps);
+ *   Wd0/Wd1: T0 T1 S0 T2 S1 ... T7 S6 S7 (S_t = Wd1 tile (0,t): 4 steps); then 8 steps of padding;
  * bias = [128 | 64 | 256 | 32] in the same order (bd1: K logits biases, then the factor bias, zeros).
  * edges (rows,64), U (rows,K) uniforms in [0,1) -> edge_feat (rows,K), dist (rows,K).  K <= 15.
  * U == NULL: the uniforms are generated inside the kernel — element row*K + k is element
