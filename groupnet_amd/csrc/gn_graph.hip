@@ -718,7 +718,7 @@ extern "C" int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int 
     if (G.H != nullptr) continue;
     const size_t per_scene = (size_t)N * (GN_FEAT + GN_FEAT + 1) * sizeof(float);
     const size_t fixed = (3 * kBlock + 32) * sizeof(float);
-    if (per_scene + fixed > kLdsBudget || N > 32767) return GN_ERR_LDS;
+    if (per_scene + fixed > 158 * 1024 || N > 32767) return GN_ERR_LDS;   // one workgroup may take the CU's 160 KiB
     int SG = 1;
     while (SG < 8 && (size_t)(2 * SG) * per_scene <= 32 * 1024 && (B + 2 * SG - 1) / (2 * SG) >= 512) SG *= 2;
     const long long edges_per_wg = (long long)SG * G.E;

@@ -78,11 +78,18 @@ class MultiScaleHGNN(nn.Module):
             raise ValueError(f"noise_u: need {1 + S} entries (pairwise + one per scale)")
         final = torch.empty((B, N, self.out_features), dtype=f.dtype, device=f.device)
         cols = [final[..., D * (1 + i):D * (2 + i)] for i in range(1 + S)]   # written in place by the last MLP
-        if S:
+        if S and ops.fused_affinity_fits(N, D):
             # one launch: affinity, incidence of every scale, f -> final[..., :D], cat(H_s), Philox bump
             _, Hs, new_H = ops.affinity_topk(f, self.hyper_scales, want_corr=False, f_out=final[..., :D],
                                              want_H_cat=True, counter=advance[0] if advance else None,
                                              counter_add=advance[1] if advance else 0)
+        elif S:
+            # large N (N*(N+68)*4 B > LDS tile): banded affinity and banded top-k launches, plain copies
+            Hs = ops.topk_incidence(ops.affinity(f), self.hyper_scales)
+            new_H = torch.cat(Hs, dim=1)
+            final[..., :D].copy_(f)
+            if advance:
+                ops.counter_add(advance[0], advance[1])
         else:
             Hs, new_H = [], None
             final[..., :D].copy_(f)

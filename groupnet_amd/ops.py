@@ -112,6 +112,11 @@ def topk_incidence(corr: Tensor, scales: Sequence[int]) -> List[Tensor]:
     return Hs
 
 
+def fused_affinity_fits(N: int, D: int, x_dim: int = 0) -> bool:
+    """Whether one scene's tile of the fused affinity+top-k launch fits its 128 KiB LDS budget."""
+    return N * (D + 4 + N + x_dim) * 4 <= 128 * 1024
+
+
 def affinity_topk(f: Optional[Tensor], scales: Sequence[int], want_corr: bool = True, f_out: Optional[Tensor] = None,
                   want_H_cat: bool = False, counter: Optional[Tensor] = None, counter_add: int = 0,
                   embed: Optional[Tuple[Tensor, Tensor, Tensor]] = None):
