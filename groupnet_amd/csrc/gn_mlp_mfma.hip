@@ -137,9 +137,7 @@ __device__ __forceinline__ void mma_tile(const f32x4* __restrict__ cur, const f3
     else
       ring.s[slot] = nxt2[(s + kP - S - LN) * kStep];
     // hipcc otherwise sinks the run-ahead load down to its use and collapses the ring to depth 1-2
-#if !defined(GN_EXP_NO_SCHED_BARRIER)
     __builtin_amdgcn_sched_barrier(0);
-#endif
   }
 }
 
@@ -524,15 +522,8 @@ struct AggGroup {
   int wpr;
 };
 __device__ __forceinline__ void relu_scale16(f32x16& a, float w) {
-#if defined(GN_EXP_NO_VALU)
-  (void)w;
-#elif defined(GN_EXP_MED3)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = __builtin_amdgcn_fmed3f(a[r], 0.f, __builtin_inff()) * w;
-#else
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f) * w;
-#endif
 }
 __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
   __shared__ float part[4][32][64];  // wpr > 1 only: [wave][register 0..31][lane]

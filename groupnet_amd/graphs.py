@@ -16,7 +16,6 @@ from typing import Optional, Tuple
 import torch
 
 from . import MS_HGNN_batch as _mods
-from . import ops
 from .multiscale import MultiScaleHGNN
 
 Tensor = torch.Tensor

@@ -21,7 +21,7 @@ container; see oracle/past_encoder_oracle.py); it is tested against that restate
 from __future__ import annotations
 
 import math
-from typing import List, Optional, Tuple
+from typing import Tuple
 
 import torch
 import torch.nn as nn
