@@ -95,3 +95,50 @@ def test_philox_known_answer():
     exp = np.array([0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8], dtype=np.uint64)
     assert np.array_equal(u, ((exp >> np.uint64(8)).astype(np.float32) * np.float32(2.0 ** -24)))
     assert u.min() >= 0.0 and u.max() < 1.0
+
+
+def _c_oracle():
+    import ctypes
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "oracle", "_build", "liboracle_topk.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(root, "oracle")])
+    lib = ctypes.CDLL(so)
+    lib.gn_oracle_topk_incidence.restype = ctypes.c_int
+    lib.gn_oracle_topk_incidence.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 3
+    return lib
+
+
+def _c_topk(lib, corr, s):
+    B, N = corr.shape[:2]
+    corr = np.ascontiguousarray(corr, dtype=np.float32)
+    H = np.empty((B, 1 if s == N else N, N), dtype=np.float32)
+    rc = lib.gn_oracle_topk_incidence(corr.ctypes.data, H.ctypes.data, B, N, s)
+    return rc, H
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_c_oracle_topk_matches_reference_incidence(name):
+    """The plain-C restatement of the index work (k rounds of arg-max) reproduces every golden H bit
+    for bit, and agrees with the rank-count statement the HIP kernel implements."""
+    lib = _c_oracle()
+    c = load_case(name)
+    for s in c["scales"].tolist():
+        rc, H = _c_topk(lib, c["corr"], s)
+        assert rc == 0 and np.array_equal(H, c[f"hyper{s}_H"]), (name, s)
+
+
+def test_c_oracle_topk_ties_nan_range():
+    lib = _c_oracle()
+    corr = np.array([[[1.0, 1.0, 0.5, 1.0], [0.0, np.nan, 2.0, 2.0], [3.0, 2.0, 1.0, 0.0], [0.0] * 4]], dtype=np.float32)
+    for s in (0, 1, 2, 3, 4):
+        rc, H = _c_topk(lib, corr, s)
+        assert rc == 0 and np.array_equal(H, O.topk_incidence_ranked(torch.from_numpy(corr), s).numpy()), s
+    assert _c_topk(lib, corr, 5)[0] == -1
+    rng = np.random.default_rng(0)
+    big = rng.integers(0, 4, size=(3, 40, 40)).astype(np.float32)      # heavy ties
+    for s in (1, 7, 39):
+        rc, H = _c_topk(lib, big, s)
+        assert np.array_equal(H, O.topk_incidence_ranked(torch.from_numpy(big), s).numpy())

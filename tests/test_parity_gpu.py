@@ -666,3 +666,20 @@ def test_multiscale_block_n256_runs():
         assert bool((H[:, i * N:(i + 1) * N].sum(-1) == s).all())
     # hyper features do not depend on the noise position of the OTHER scene's rows: scene order swap
     assert out2.shape == out.shape
+
+
+def test_topk_heavy_ties_against_c_oracle():
+    """Index work must be bit-exact: small-integer affinities (many exact ties, some NaN) through the HIP
+    rank kernel vs the plain-C arg-max oracle (oracle/topk_incidence.c), fused and stand-alone form."""
+    from groupnet_amd import ops
+    from test_oracle_golden import _c_oracle, _c_topk
+    lib = _c_oracle()
+    rng = np.random.default_rng(1)
+    for B, N in ((7, 11), (3, 64), (2, 129)):
+        corr = rng.integers(0, 3, size=(B, N, N)).astype(np.float32)
+        corr[0, 0, 1] = np.nan
+        scales = [1, 2, N // 2, N - 1, N]
+        Hs = ops.topk_incidence(to_dev(corr), scales)
+        for s, H in zip(scales, Hs):
+            rc, want = _c_topk(lib, corr, s)
+            assert rc == 0 and np.array_equal(H.cpu().numpy(), want), (B, N, s)
