@@ -94,7 +94,10 @@ __device__ __forceinline__ f32x16 load_bias_tile(const float* __restrict__ bias_
   return b;
 }
 
-constexpr int kP = 8;          // ring depth in steps
+#ifndef GN_RING_DEPTH
+#define GN_RING_DEPTH 8
+#endif
+constexpr int kP = GN_RING_DEPTH;  // ring depth in steps
 constexpr int kStep = 64;      // f32x4 elements per step (one per lane)
 struct WRing {
   f32x4 s[kP];
