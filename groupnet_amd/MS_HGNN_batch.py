@@ -76,6 +76,13 @@ def _noise_iter(noise_u: Union[None, Tensor, Sequence[Tensor]]) -> Optional[Iter
     return iter(list(noise_u))
 
 
+def _needs_grad(mod: nn.Module, *inputs: Optional[Tensor]) -> bool:
+    """True when autograd is recording and the call involves anything that wants a gradient."""
+    if not torch.is_grad_enabled():
+        return False
+    return any(t is not None and t.requires_grad for t in inputs) or any(p.requires_grad for p in mod.parameters())
+
+
 _warned_grad = False
 
 
@@ -313,6 +320,15 @@ class _MessagePassing(nn.Module):
              ) -> Tuple[Tensor, Tensor]:
         return run_message_passing([self], [h], [H], [noise_u], [out])[0]
 
+    def _forward_autograd(self, h: Tensor, H: Optional[Tensor], noise_u, out: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+        """Training path: fused forward + HIP backward through torch.autograd."""
+        from .backward import MSHGNNFunction
+        if self.nmp_layers != 1:
+            raise NotImplementedError("the backward is built for nmp_layers == 1 (every caller of the reference)")
+        if out is not None:
+            raise ValueError("out= is an inference-time extra; under autograd the module returns a new tensor")
+        return MSHGNNFunction.apply(self, H, noise_u, h, *self.parameters())
+
 
 def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor], Hs: Sequence[Optional[Tensor]],
                         noises: Sequence, outs: Sequence[Optional[Tensor]]) -> List[Tuple[Tensor, Tensor]]:
@@ -429,10 +445,12 @@ class MS_HGNN_oridinary(_MessagePassing):
 
     def forward(self, h_states, noise_u=None, out=None):
         """``out`` (optional): where node_feat is written, e.g. a column block of the caller's
-        concatenated feature tensor."""
-        _check_forward_only(h_states)
+        concatenated feature tensor.  Under autograd (an input or a parameter requires grad) the call
+        goes through `groupnet_amd.backward.MSHGNNFunction`: same fused forward, HIP backward."""
         ops._req(h_states, "h_states", (None, None, self.h_dim))
         N = h_states.shape[1]
+        if h_states.shape[0] and N and _needs_grad(self, h_states):
+            return self._forward_autograd(h_states, None, noise_u, out)
         if h_states.shape[0] == 0 or N == 0:      # empty batch: nothing to launch
             nf = out if out is not None else h_states.new_empty((h_states.shape[0], N, self.bottleneck_dim))
             return nf, h_states.new_empty((h_states.shape[0], N * N, self.edge_types))
@@ -479,8 +497,13 @@ class MS_HGNN_hyper(_MessagePassing):
     def forward(self, h_states, corr, noise_u=None, H=None, out=None):
         """``H`` (optional) lets a caller that already built the incidence for every scale in one
         fused launch (``ops.affinity_topk``) hand it in; by default it is built here from ``corr``."""
-        _check_forward_only(h_states, corr)
         ops._req(h_states, "h_states", (None, None, self.h_dim))
+        if h_states.shape[0] and _needs_grad(self, h_states):
+            # H is a constant of the backward (top-k selection has no gradient; corr is only used to build it)
+            if H is None:
+                H = self.init_adj_attention(h_states.detach(), corr.detach(), scale_factor=self.scale)
+            node_feat, factor = self._forward_autograd(h_states, H, noise_u, out)
+            return node_feat, factor, H
         if h_states.shape[0] == 0:                  # empty batch: nothing to launch
             B, N = h_states.shape[0], h_states.shape[1]
             if self.scale > N:

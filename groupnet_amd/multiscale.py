@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .MS_HGNN_batch import MS_HGNN_hyper, MS_HGNN_oridinary, _check_forward_only, run_message_passing
+from .MS_HGNN_batch import MS_HGNN_hyper, MS_HGNN_oridinary, _needs_grad, run_message_passing
 
 Tensor = torch.Tensor
 
@@ -65,11 +65,24 @@ class MultiScaleHGNN(nn.Module):
         list of ``nmp_layers`` tensors; default draws as the modules do (reference order).
         ``advance`` = (counter, n): add n to the device Philox counter at the START of this forward
         (used by the captured graph so that every replay draws fresh noise)."""
-        _check_forward_only(f)
         ops._req(f, "f", (None, None, self.h_dim))
         B, N, D = f.shape
         S = len(self.hyper_scales)
         nmp = self.interaction.nmp_layers
+        if _needs_grad(self, f):
+            # training: module by module through autograd (fused forward, HIP backward each); the concat
+            # is an ordinary differentiable torch.cat
+            if S:
+                _, Hs, new_H = ops.affinity_topk(f.detach(), self.hyper_scales, want_corr=False, want_H_cat=True)
+            else:
+                Hs, new_H = [], None
+            if advance:
+                ops.counter_add(advance[0], advance[1])
+            nz = noise_u if noise_u is not None else [None] * (1 + S)
+            feats = [f, self.interaction(f, noise_u=nz[0])[0]]
+            for m, H, u in zip(self.interaction_hyper, Hs, nz[1:]):
+                feats.append(m(f, None, noise_u=u, H=H)[0])
+            return torch.cat(feats, dim=-1), new_H
         if noise_u is None:
             # reference order: every draw of the pairwise module first, then scale by scale
             from .MS_HGNN_batch import _draw_uniform

@@ -278,6 +278,44 @@ typedef struct {
 int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
                 int N, float divisor, gn_stream_t stream);
 
+/* ---- backward (training) building blocks — SURVEY.md §8f rank 2 -------------------------------
+ * train_hyper_nba.py:116 back-propagates through the two modules.  The backward of the path is
+ * assembled (groupnet_amd/backward.py) from these generic kernels plus the forward gather / scatter
+ * kernels, which are each other's adjoints.  All pointers device fp32, row-major.
+ *
+ * gn_gemm_f32: C (M x N, ldc) = beta*C + alpha*op(A) op(B) [+ bias[n]] [relu] [zeroed where mask[m][n] <= 0];
+ *   op(A) = A (M x K, lda) or, transA, A^T with A stored (K x M, lda); op(B) = B (K x N, ldb) or, transB,
+ *   B^T with B stored (N x K, ldb).  With few output tiles and K >= 4096 (weight gradients dW = dY^T X)
+ *   K is split over workgroups and partial sums are added atomically (then no bias/relu/mask).
+ * gn_colsum_f32: out[c] += sum_r X[r][c]   (bias gradients; out must hold the running sum / zeros).
+ * gn_rowscale_f32: dst[r][:] = s[r*lds + off] * src[r][:];  gn_rowdot_f32: out[r*ldo + off] = <a[r], b[r]>.
+ * gn_gumbel_bwd_f32: back through edge_feat = sigmoid(f) * dist, dist = softmax((logits + g)/tau)
+ *   (model/MS_HGNN_batch.py:45-50): dist (rows,K), lgf (rows,ldl) whose column K is f, def = d edge_feat,
+ *   gdist = d dist or NULL -> dlgf (rows,ldl): columns 0..K-1 = d logits, column K = d f, rest 0.
+ * gn_node2edge_bwd_f32: back through gn_node2edge_f32 for an explicit H (B,E,N): given dedges (B,E,64)
+ *   ADDS into dxp (B,N,64), dpq (B,N,64), dw2 (32), db2 (1) (atomics; zero them first). */
+int gn_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                int transA, int transB, const float* bias, const float* mask, int ldmask, int relu,
+                float alpha, float beta, gn_stream_t stream);
+/* out (rows x cols, ldo) = alpha * a (rows x cols, lda) + beta * out — slices, scalings and sums of
+ * gradients without leaving the library. */
+int gn_axpby2d_f32(float* out, int ldo, const float* a, int lda, long long rows, int cols, float alpha,
+                   float beta, gn_stream_t stream);
+/* ef[r][k] = sigmoid(lgf[r][K]) * dist[r][k]: edge_feat of MLP_dict_softmax from dist and the factor
+ * pre-activation (column K of lgf (rows, ldl)). */
+int gn_gumbel_ef_f32(const float* dist, const float* lgf, float* ef, long long rows, int K, int ldl,
+                     gn_stream_t stream);
+int gn_colsum_f32(const float* X, float* out, int rows, int cols, int ld, gn_stream_t stream);
+int gn_rowscale_f32(float* dst, const float* src, const float* s, long long rows, int cols, int lds, int off,
+                    gn_stream_t stream);
+int gn_rowdot_f32(const float* a, const float* b, float* out, long long rows, int cols, int ldo, int off,
+                  gn_stream_t stream);
+int gn_gumbel_bwd_f32(const float* dist, const float* lgf, const float* def, const float* gdist, float* dlgf,
+                      long long rows, int K, int ldl, float tau, gn_stream_t stream);
+int gn_node2edge_bwd_f32(const float* xp, const float* pq, const float* H, const float* w2, float b2,
+                         const float* dedges, float* dxp, float* dpq, float* dw2, float* db2, int B, int N,
+                         int E, gn_stream_t stream);
+
 /* ---- device noise (build's own; the reference draws torch.rand on the host) --------------------
  * U[i] = Philox4x32-10(counter = (i + offset) / 4, key = seed)[(i + offset) % 4] >> 8, scaled to
  * [0,1).  Lets a sharded run draw exactly the rows of the full-batch stream it owns.
