@@ -323,22 +323,23 @@ class _MessagePassing(nn.Module):
     def _forward_autograd(self, h: Tensor, H: Optional[Tensor], noise_u, out: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
         """Training path: fused forward + HIP backward through torch.autograd."""
         from .backward import MSHGNNFunction
-        if self.nmp_layers != 1:
-            raise NotImplementedError("the backward is built for nmp_layers == 1 (every caller of the reference)")
         if out is not None:
             raise ValueError("out= is an inference-time extra; under autograd the module returns a new tensor")
-        return MSHGNNFunction.apply(self, H, noise_u, h, *self.parameters())
+        return MSHGNNFunction.apply((self,), (H,), (noise_u,), h, *self.parameters())
 
 
 def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor], Hs: Sequence[Optional[Tensor]],
-                        noises: Sequence, outs: Sequence[Optional[Tensor]]) -> List[Tuple[Tensor, Tensor]]:
+                        noises: Sequence, outs: Sequence[Optional[Tensor]], traces=None
+                        ) -> List[Tuple[Tensor, Tensor]]:
     """The message-passing rounds of SEVERAL modules over the same scenes, stage by stage, each stage
     ONE grouped launch (model/MS_HGNN_batch.py:174-195 and :425-441 for every module at once).
 
     mods[i] runs on hs[i] (B,N,64) with incidence Hs[i] (None = the implicit pairwise graph);
     noises[i] is None (draw), a tensor / PhiloxNoise, or a list of nmp_layers of them; outs[i]
     optionally receives node_feat.  Returns [(node_feat, factors)] per module.  All modules must
-    share nmp_layers and bottleneck_dim (they do in every caller of the reference)."""
+    share nmp_layers and bottleneck_dim (they do in every caller of the reference).
+    `traces` (training): one `backward.ModuleTrace` per module, which receives the node features entering
+    every round and the dist every round sampled — all the backward needs besides the inputs."""
     n = len(mods)
     if not (n == len(hs) == len(Hs) == len(noises) == len(outs)) or n == 0:
         raise ValueError("run_message_passing: one h, H, noise and out per module")
@@ -395,6 +396,9 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
 
     res = edge_mlp([m.nmp_mlp_start for m in mods], node2edge(hs, 0), True)
     edge_feats, factors = [r[0] for r in res], [r[1] for r in res]
+    if traces is not None:
+        for t, r in zip(traces, res):
+            t.dists.append(r[1])
     node_feats, idx = list(hs), 0
     for l in range(2 * (nmp - 1)):
         stages = [m.nmp_mlps[l] for m in mods]
@@ -402,8 +406,15 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
             agg = edge2node(edge_feats, node_feats, idx)
             node_feats = ops.mlp2_grouped([(a, m._packed_mlp2(st), None) for a, m, st in zip(agg, mods, stages)])
             idx += 1
+            if traces is not None:
+                for t, x in zip(traces, node_feats):
+                    t.xs.append(x)
         else:
-            edge_feats = [r[0] for r in edge_mlp(stages, node2edge(node_feats, idx), False)]
+            res = edge_mlp(stages, node2edge(node_feats, idx), traces is not None)
+            edge_feats = [r[0] for r in res]
+            if traces is not None:
+                for t, r in zip(traces, res):
+                    t.dists.append(r[1])
     agg = edge2node(edge_feats, node_feats, idx)
     ends = [(a, m._packed_mlp2(m.nmp_mlp_end), o) for a, m, o in zip(agg, mods, outs)]
     # the last MLP writes in place when `out` is given; grouped when every group has the same stride

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -61,6 +61,13 @@ class BlockExtras(ctypes.Structure):    # gn_block_extras_t
                 ("x_raw", _P), ("x_dim", _I), ("M", _P), ("c", _P), ("f_contig", _P)]
 
 
+class GemmDesc(ctypes.Structure):      # gn_gemm_desc_t
+    _fields_ = [("A", _P), ("B", _P), ("C", _P), ("bias", _P), ("mask", _P), ("rs", _P), ("colsum", _P),
+                ("M", _I), ("N", _I), ("K", _I), ("lda", _I), ("ldb", _I), ("ldc", _I), ("ldmask", _I), ("rs_ld", _I),
+                ("flags", _I), ("alpha", _F), ("beta", _F)]
+
+
+GEMM_TRANS_A, GEMM_TRANS_B, GEMM_RELU, GEMM_ACCUM = 1, 2, 4, 8
 MAX_GROUPS = 10
 
 # name -> (restype, argtypes); mirrors include/groupnet_hip.h one to one
@@ -82,6 +89,8 @@ SIGNATURES = {
     "gn_agg_scatter_f32": (_I, [ctypes.POINTER(ScatterGroup), _I, _I, _I, _F, _P]),
     "gn_mlp2_f32": (_I, [ctypes.POINTER(Mlp2Group), _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "gn_gemm_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _F, _P]),
+    "gn_gemm_grouped_f32": (_I, [ctypes.POINTER(GemmDesc), _I, _P]),
+    "gn_typed_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, ctypes.c_longlong, _I, _I, _P]),
     "gn_axpby2d_f32": (_I, [_P, _I, _P, _I, ctypes.c_longlong, _I, _F, _F, _P]),
     "gn_gumbel_ef_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _I, _I, _P]),
     "gn_colsum_f32": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -1,80 +1,97 @@
-"""Backward of one MS-HGNN module assembled from HIP building blocks.
+"""Backward of the MS-HGNN modules on HIP, behind torch.autograd.
 
 `train_hyper_nba.py:116` back-propagates through `MS_HGNN_oridinary` / `MS_HGNN_hyper`.  The forward
-of the drop-in modules is the fused matrix-core path; when a gradient is needed the module goes through
-`MSHGNNFunction`: forward = that same fused path, backward = this file — the chain rule written out
-stage by stage (model/MS_HGNN_batch.py:41-53, 116-141, 247-268, 357-370), every tensor operation a kernel
-of libgroupnet_hip.so (`gn_gemm_f32`, `gn_colsum_f32`, `gn_rowscale_f32`, `gn_rowdot_f32`,
-`gn_gumbel_bwd_f32`, `gn_gumbel_ef_f32`, `gn_node2edge_bwd_f32`, `gn_axpby2d_f32` and the forward
-gather / scatter / node2edge / typed-MLP kernels).  Hidden activations are not kept by the fused forward,
-so the backward first re-computes them layer by layer with the generic GEMM.
+of the drop-in modules is the fused matrix-core path; when a gradient is needed a call goes through
+`MSHGNNFunction`: forward = that same fused path (keeping only the node features entering each
+message-passing round and the `dist` each round sampled, which carries the Gumbel noise), backward =
+this file — the chain rule of model/MS_HGNN_batch.py:41-53, 116-141, 247-268, 357-370 written out stage
+by stage for SEVERAL modules at once, every stage one grouped launch of libgroupnet_hip.so:
 
-Scope: `nmp_layers == 1` (every caller of the reference), explicit incidence H — the pairwise graph is
-materialised as its (B, N*N, N) incidence (weights 1, self-loops 2) for the backward, which bounds the
-trainable pairwise module to moderate N.  Correctness first; this path is not tuned.
+  * all dense contractions (re-computation of hidden activations, dX = dY W, dW = dY^T X with the bias
+    gradient as a side output) are problems of `gn_gemm_grouped_f32` — fp32 matrix cores, many problems
+    per launch; every weight gradient of a round goes into ONE launch at the end of the round;
+  * the K typed MLPs of the aggregation are handled as one wide layer (hidden (rows, K*128)) plus
+    `gn_typed_bwd_f32`;
+  * `gn_gumbel_bwd_f32`, `gn_node2edge_bwd_f32` for the two non-GEMM stages; gather and scatter are each
+    other's adjoints and reuse the forward kernels.
+
+A round j of a module is two blocks: x_j --node2edge_j, edge MLP_j--> (ef_j, dist_j) and
+(ef_j, x_j) --edge2node_j, MLP--> x_{j+1} (or node_feat).  `nmp_layers > 1` (:186-194, :432-440) is
+the same two blocks repeated, walked backwards.
 """
 from __future__ import annotations
 
 import ctypes
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from ._lib import _P, check, load, stream_handle
 
 Tensor = torch.Tensor
 _TAU = 0.5
+_HID = 128           # hidden width of the typed aggregation MLPs (model/MS_HGNN_batch.py:253-255)
+_LGF_LD = 32         # leading dimension of the (logits | factor pre-activation) buffer
 
 
-# ---- thin faces of the generic kernels -------------------------------------------------------------
 def _p(t: Optional[Tensor]):
     return _P(0 if t is None else t.data_ptr())
 
 
+class GemmBatch:
+    """Collects GEMM problems (2-D row-major views, unit column stride) and runs them as grouped launches."""
+
+    def __init__(self):
+        self.descs: List[_lib.GemmDesc] = []
+        self.keep: List[Tensor] = []
+        self.device = None
+
+    def add(self, A: Tensor, Bm: Tensor, C: Tensor, tA=False, tB=False, bias=None, mask=None, relu=False, alpha=1.0,
+            beta=0.0, rs: Optional[Tensor] = None, colsum: Optional[Tensor] = None, accum=False) -> Tensor:
+        for t in (A, Bm, C) + ((mask,) if mask is not None else ()):
+            if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or t.dtype != torch.float32:
+                raise ValueError("gemm: 2-D fp32 views with unit column stride")
+        M, K = (A.shape[1], A.shape[0]) if tA else (A.shape[0], A.shape[1])
+        K2, N = (Bm.shape[1], Bm.shape[0]) if tB else (Bm.shape[0], Bm.shape[1])
+        if K != K2 or tuple(C.shape) != (M, N) or (mask is not None and tuple(mask.shape) != (M, N)):
+            raise ValueError(f"gemm: ({M},{K}) x ({K2},{N}) -> {tuple(C.shape)}")
+        if rs is not None and (rs.dim() != 1 or rs.shape[0] != A.shape[0]):
+            raise ValueError("gemm: rs scales the stored rows of A")
+        if colsum is not None and (not tA or colsum.numel() != M or not colsum.is_contiguous()):
+            raise ValueError("gemm: colsum needs transA and M contiguous entries")
+        flags = (_lib.GEMM_TRANS_A if tA else 0) | (_lib.GEMM_TRANS_B if tB else 0) | \
+                (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_ACCUM if accum else 0)
+        ld = lambda t: max(t.stride(0), t.shape[1])
+        self.descs.append(_lib.GemmDesc(A.data_ptr(), Bm.data_ptr(), C.data_ptr(), _p(bias).value, _p(mask).value,
+                                        _p(rs).value, _p(colsum).value, M, N, K, ld(A), ld(Bm), ld(C),
+                                        0 if mask is None else ld(mask), 0 if rs is None else rs.stride(0), flags,
+                                        float(alpha), float(beta)))
+        self.keep += [t for t in (A, Bm, C, bias, mask, rs, colsum) if t is not None]
+        self.device = A.device
+        return C
+
+    def run(self) -> None:
+        if not self.descs:
+            return
+        arr = (_lib.GemmDesc * len(self.descs))(*self.descs)
+        with torch.cuda.device(self.device):
+            check(load().gn_gemm_grouped_f32(arr, len(self.descs), stream_handle()), "gn_gemm_grouped_f32")
+        self.descs, self.keep = [], []
+
+
 def gemm(A: Tensor, Bm: Tensor, transA=False, transB=False, bias=None, mask=None, relu=False, alpha=1.0,
          out: Optional[Tensor] = None, beta=0.0) -> Tensor:
-    """out (M,N) = beta*out + alpha*op(A) op(B) (+bias) (relu) (zeroed where mask <= 0); 2-D row-major views."""
-    assert A.dim() == 2 and Bm.dim() == 2 and A.stride(1) == 1 and Bm.stride(1) == 1
-    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
-    K2, N = (Bm.shape[1], Bm.shape[0]) if transB else (Bm.shape[0], Bm.shape[1])
-    if K != K2:
-        raise ValueError(f"gemm: inner dimensions {K} vs {K2}")
+    """out (M,N) = beta*out + alpha*op(A) op(B) (+bias) (relu) (zeroed where mask <= 0) — one problem."""
+    M = A.shape[1] if transA else A.shape[0]
+    N = Bm.shape[0] if transB else Bm.shape[1]
     if out is None:
-        out = torch.empty((M, N), dtype=A.dtype, device=A.device)
-        beta = 0.0
-    assert out.shape == (M, N) and out.stride(1) == 1
-    if mask is not None:
-        assert mask.shape == (M, N) and mask.stride(1) == 1
-    with torch.cuda.device(A.device):
-        check(load().gn_gemm_f32(_p(A), _p(Bm), _p(out), M, N, K, A.stride(0), Bm.stride(0), out.stride(0), int(transA),
-                                 int(transB), _p(bias), _p(mask), 0 if mask is None else mask.stride(0), int(relu),
-                                 float(alpha), float(beta), stream_handle()), "gn_gemm_f32")
+        out, beta = torch.empty((M, N), dtype=A.dtype, device=A.device), 0.0
+    gb = GemmBatch()
+    gb.add(A, Bm, out, transA, transB, bias, mask, relu, alpha, beta)
+    gb.run()
     return out
-
-
-def colsum(X: Tensor) -> Tensor:
-    out = torch.zeros(X.shape[1], dtype=X.dtype, device=X.device)
-    with torch.cuda.device(X.device):
-        check(load().gn_colsum_f32(_p(X), _p(out), X.shape[0], X.shape[1], X.stride(0), stream_handle()), "gn_colsum_f32")
-    return out
-
-
-def rowscale(src: Tensor, s: Tensor, off: int) -> Tensor:
-    """dst[r,:] = s[r, off] * src[r,:]"""
-    dst = torch.empty_like(src)
-    with torch.cuda.device(src.device):
-        check(load().gn_rowscale_f32(_p(dst), _p(src), _p(s), src.shape[0], src.shape[1], s.stride(0), off,
-                                     stream_handle()), "gn_rowscale_f32")
-    return dst
-
-
-def rowdot_into(a: Tensor, b: Tensor, out: Tensor, off: int) -> None:
-    """out[r, off] = <a[r], b[r]>"""
-    with torch.cuda.device(a.device):
-        check(load().gn_rowdot_f32(_p(a), _p(b), _p(out), a.shape[0], a.shape[1], out.stride(0), off, stream_handle()),
-              "gn_rowdot_f32")
 
 
 def axpby(out: Tensor, a: Tensor, alpha=1.0, beta=0.0) -> Tensor:
@@ -86,14 +103,10 @@ def axpby(out: Tensor, a: Tensor, alpha=1.0, beta=0.0) -> Tensor:
     return out
 
 
-def _lin(X: Tensor, layer: nn.Linear, relu=False) -> Tensor:
-    return gemm(X, layer.weight.detach(), transB=True, bias=layer.bias.detach(), relu=relu)
-
-
 def pairwise_incidence(B: int, N: int, device, dtype=torch.float32) -> Tensor:
     """The (B, N*N, N) incidence rel_rec + rel_send of the pairwise graph (model/MS_HGNN_batch.py:118,
     143-160): edge e = i*N + j has weight 1 on i and on j, 2 when i == j.  A constant; only the backward
-    materialises it."""
+    of node2edge materialises it."""
     e = torch.arange(N * N, device=device)
     H = torch.zeros(N * N, N, dtype=dtype, device=device)
     H[e, e % N] += 1
@@ -101,164 +114,306 @@ def pairwise_incidence(B: int, N: int, device, dtype=torch.float32) -> Tensor:
     return H[None].expand(B, -1, -1).contiguous()
 
 
-# ---- the backward of one module ----------------------------------------------------------------------
-def module_backward(mod, h: Tensor, H: Tensor, dist: Tensor, g_nf: Optional[Tensor], g_dist: Optional[Tensor]
-                    ) -> Tuple[Tensor, Dict[nn.Parameter, Tensor]]:
-    """Gradients of (node_feat, factors) of one module w.r.t. h_states and its parameters.
+class _Pool:
+    """Zero-initialised scratch handed out in slices: every accumulate-by-atomics target of a round comes
+    from one fill instead of one fill each."""
 
-    h (B,N,64); H (B,E,N) explicit; dist = the `factors` the forward returned (B,E,K) (it carries the
-    Gumbel noise, which is a constant of the backward); g_nf (B,N,bottleneck) / g_dist (B,E,K) the incoming
-    gradients (either may be None)."""
-    if mod.nmp_layers != 1:
-        raise NotImplementedError("backward is built for nmp_layers == 1")
-    B, N, D = h.shape
-    E, K = H.shape[1], mod.edge_types
-    dev = h.device
-    grads: Dict[nn.Parameter, Tensor] = {}
-    h2 = h.reshape(B * N, D)
-    s0, s1 = mod.node2edge_start_mlp[0].layers
-    a0, a1 = mod.attention_mlp[0].layers
-    st = mod.nmp_mlp_start
-    i0, i1 = st.init_MLP.layers
-    d0, d1 = st.MLP_distribution.layers
-    f0, f1 = st.MLP_factor.layers
-    agg_mod = mod.edge_aggregation_list[0]
-    e0, e1 = mod.nmp_mlp_end.layers
+    def __init__(self, numel: int, device):
+        self.buf = torch.zeros(numel, dtype=torch.float32, device=device)
+        self.used = 0
+
+    def take(self, *shape: int) -> Tensor:
+        n = 1
+        for s in shape:
+            n *= s
+        n4 = (n + 3) // 4 * 4
+        if self.used + n4 > self.buf.numel():
+            return torch.zeros(shape, dtype=torch.float32, device=self.buf.device)
+        out = self.buf[self.used:self.used + n].view(*shape)
+        self.used += n4
+        return out
+
+
+class ModuleTrace:
+    """What one module's fused forward keeps for its backward."""
+
+    def __init__(self, mod, h: Tensor, H: Optional[Tensor]):
+        self.mod, self.H = mod, H
+        self.xs: List[Tensor] = [h]          # node features entering round j
+        self.dists: List[Tensor] = []        # dist of round j (B,E,K)
+
+
+def _round_layers(mod, j: int):
+    L = mod.nmp_layers - 1
+    stage = mod.nmp_mlp_start if j == 0 else mod.nmp_mlps[2 * j - 1]
+    tail = mod.nmp_mlp_end if j == L else mod.nmp_mlps[2 * j]
+    return (mod.node2edge_start_mlp[j].layers, mod.attention_mlp[j].layers, stage, mod.edge_aggregation_list[j],
+            tail.layers)
+
+
+def _typed_weights(agg) -> dict:
+    """The K typed MLPs of one edge_aggregation as one wide layer (cached per parameter version)."""
+    from .MS_HGNN_batch import _param_key
+    key = _param_key(agg.agg_mlp.parameters())
+    hit = agg.__dict__.get("_bwd_cat")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            l0 = [m.layers[0] for m in agg.agg_mlp]
+            l1 = [m.layers[1] for m in agg.agg_mlp]
+            cat = dict(W1cat=torch.cat([l.weight for l in l0], 0).contiguous(),       # (K*128, 64)
+                       b1cat=torch.cat([l.bias for l in l0], 0).contiguous(),         # (K*128)
+                       W2cat=torch.cat([l.weight for l in l1], 1).contiguous(),       # (64, K*128)
+                       b2mat=torch.stack([l.bias for l in l1], 0).contiguous())       # (K, 64)
+        agg.__dict__["_bwd_cat"] = (key, cat)
+        hit = agg.__dict__["_bwd_cat"]
+    return hit[1]
+
+
+def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optional[Tensor]],
+                   g_dists: Sequence[Optional[Tensor]], grads: Dict[nn.Parameter, Tensor]) -> List[Tensor]:
+    """Back through round j of several modules at once.
+
+    g_ys[i] = gradient w.r.t. the output of round j's edge2node + MLP block (node_feat for the last round),
+    g_dists[i] = gradient w.r.t. dist_j (the returned `factors` for round 0), either may be None.
+    Adds the parameter gradients to `grads`, returns d x_j per module."""
+    n = len(traces)
+    W = lambda l: l.weight.detach()
+    b = lambda l: l.bias.detach()
+    D = ops.FEAT
+    S = []           # per-module state of this round
+    for t, g_y, g_d in zip(traces, g_ys, g_dists):
+        mod, x = t.mod, t.xs[j]
+        B, N, _ = x.shape
+        Hx = t.H
+        if Hx is None and "_pair_H" not in t.__dict__:
+            t._pair_H = pairwise_incidence(B, N, x.device, x.dtype)
+        E = N * N if Hx is None else Hx.shape[1]
+        K = mod.edge_types
+        (s0, s1), (a0, a1), st, agg, (e0, e1) = _round_layers(mod, j)
+        npar = sum(p.numel() for m in (mod.node2edge_start_mlp[j], mod.attention_mlp[j], st, agg,
+                                       nn.ModuleList([e0, e1])) for p in m.parameters())
+        S.append(dict(mod=mod, x=x, x2=x.reshape(B * N, D), H=Hx, Hexp=Hx if Hx is not None else t._pair_H, B=B, N=N,
+                      E=E, K=K, R=B * E, s0=s0, s1=s1, a0=a0, a1=a1, i=st.init_MLP.layers, d=st.MLP_distribution.layers,
+                      f=st.MLP_factor.layers, agg=agg, tw=_typed_weights(agg), e0=e0, e1=e1,
+                      dist=t.dists[j].reshape(B * E, K), g_y=None if g_y is None else g_y.reshape(B * N, -1).contiguous(),
+                      g_d=None if g_d is None else g_d.reshape(B * E, K).contiguous(),
+                      pool=_Pool(npar + 2 * B * N * D + B * E * (K + D) + 4096, x.device)))
+    dev = S[0]["x"].device
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    gb = GemmBatch()
+
+    def stage(fn):
+        for c in S:
+            fn(c)
+        gb.run()
+
     with torch.no_grad():
         # ---------------- re-computation of what the fused forward did not keep ----------------
-        x1 = _lin(h2, s0, relu=True)                                   # (BN,256)
-        xp = _lin(x1, s1)                                              # (BN,64)
-        Wpq = torch.cat((a0.weight[:, :D], a0.weight[:, D:]), 0).detach().contiguous()      # (64,64): [P ; Qn]
-        bpq = torch.cat((a0.bias, torch.zeros_like(a0.bias)), 0).detach().contiguous()
-        pq = gemm(xp, Wpq, transB=True, bias=bpq)
-        w2 = a1.weight.detach()[0].contiguous()
-        b2 = float(a1.bias.detach()[0].item())
-        edges = ops.node2edge(xp.view(B, N, D), pq.view(B, N, D), H, w2, b2)                 # (B,E,64)
-        edges2 = edges.view(B * E, D)
-        z1 = _lin(edges2, i0, relu=True)                               # (BE,128)
-        z = _lin(z1, i1)                                               # (BE,64)
-        Wd0 = torch.cat((d0.weight, f0.weight), 0).detach().contiguous()                     # (256,64)
-        bd0 = torch.cat((d0.bias, f0.bias), 0).detach().contiguous()
-        dh1 = gemm(z, Wd0, transB=True, bias=bd0, relu=True)           # (BE,256)
-        Wd1 = torch.zeros(32, 256, dtype=h.dtype, device=dev)
-        Wd1[:K, :128] = d1.weight.detach()
-        Wd1[K, 128:] = f1.weight.detach()[0]
-        bd1 = torch.zeros(32, dtype=h.dtype, device=dev)
-        bd1[:K] = d1.bias.detach()
-        bd1[K] = f1.bias.detach()[0]
-        lgf = gemm(dh1, Wd1, transB=True, bias=bd1)                    # (BE,32): K logits, then the factor pre-activation
-        dist2 = dist.reshape(B * E, K).contiguous()
-        ef = torch.empty_like(dist2)
-        with torch.cuda.device(dev):
-            check(load().gn_gumbel_ef_f32(_p(dist2), _p(lgf), _p(ef), B * E, K, 32, stream_handle()), "gn_gumbel_ef_f32")
-        eo = ops.agg_gather(h, H)                                      # (B,E,64)
-        eo2 = eo.view(B * E, D)
-        l0s = [m.layers[0] for m in agg_mod.agg_mlp]
-        l1s = [m.layers[1] for m in agg_mod.agg_mlp]
-        hks = [_lin(eo2, l, relu=True) for l in l0s]                   # K x (BE,128)
-        mks = [_lin(hk, l) for hk, l in zip(hks, l1s)]                 # K x (BE,64)
-        feat = ops.agg_mlp(eo, ef.view(B, E, K), agg_mod._packed(), K)                       # (B,E,64)
-        agg = ops.agg_scatter(feat, H, h)                              # (B,N,128) = cat(H^T feat, ori)/N
-        agg2 = agg.view(B * N, 2 * D)
-        y1 = _lin(agg2, e0, relu=True)                                 # (BN,128)
+        stage(lambda c: c.update(x1=gb.add(c["x2"], W(c["s0"]), new(c["B"] * c["N"], 256), tB=True, bias=b(c["s0"]),
+                                           relu=True)))
+        stage(lambda c: c.update(xp=gb.add(c["x1"], W(c["s1"]), new(c["B"] * c["N"], D), tB=True, bias=b(c["s1"]))))
 
-        # ---------------- backward ----------------
-        dh = torch.zeros_like(h2)
-        def_ = torch.zeros((B * E, K), dtype=h.dtype, device=dev)
-        if g_nf is not None:
-            g = g_nf.reshape(B * N, -1).contiguous()
-            dy1 = gemm(g, e1.weight.detach(), mask=y1)                 # (BN,128)
-            grads[e1.weight] = gemm(g, y1, transA=True)
-            grads[e1.bias] = colsum(g)
-            daggN = gemm(dy1, e0.weight.detach(), alpha=1.0 / N)       # d(agg) / N  (BN,128)
-            grads[e0.weight] = gemm(dy1, agg2, transA=True)
-            grads[e0.bias] = colsum(dy1)
-            axpby(dh, daggN[:, D:], 1.0, 1.0)                          # ori half of the concat
-            da = torch.empty((B * N, D), dtype=h.dtype, device=dev)
-            axpby(da, daggN[:, :D])
-            dfeat = ops.agg_gather(da.view(B, N, D), H).view(B * E, D)  # adjoint of H^T feat
-            deo = torch.zeros((B * E, D), dtype=h.dtype, device=dev)
-            for k in range(K):
-                rowdot_into(dfeat, mks[k], def_, k)                    # d ef_k = <dfeat, M_k(eo)>
-                dmk = rowscale(dfeat, ef, k)                           # ef_k * dfeat
-                dhk = gemm(dmk, l1s[k].weight.detach(), mask=hks[k])   # (BE,128)
-                gemm(dhk, l0s[k].weight.detach(), out=deo, beta=1.0)
-                grads[l1s[k].weight] = gemm(dmk, hks[k], transA=True)
-                grads[l1s[k].bias] = colsum(dmk)
-                grads[l0s[k].weight] = gemm(dhk, eo2, transA=True)
-                grads[l0s[k].bias] = colsum(dhk)
-            # eo = H ori  ->  d ori += H^T d eo   (the scatter kernel with divisor 1; its ori half is unused)
-            sc = ops.agg_scatter(deo.view(B, E, D), H, torch.zeros_like(h), divisor=1.0).view(B * N, 2 * D)
-            axpby(dh, sc[:, :D], 1.0, 1.0)
-        if g_nf is not None or g_dist is not None:
-            gd = None if g_dist is None else g_dist.reshape(B * E, K).contiguous()
-            dlgf = torch.empty((B * E, 32), dtype=h.dtype, device=dev)
+        def pq_stage(c):
+            # attention layer 0 on cat(x'_n, e0_e), split by linearity: P = W[:, :64] x' + b, Qn = W[:, 64:] x'
+            c["pq"] = new(c["B"] * c["N"], D)
+            gb.add(c["xp"], W(c["a0"])[:, :D], c["pq"][:, :32], tB=True, bias=b(c["a0"]))
+            gb.add(c["xp"], W(c["a0"])[:, D:], c["pq"][:, 32:], tB=True)
+        stage(pq_stage)
+        for c in S:
+            c["w2"] = W(c["a1"])[0].contiguous()
+            c["b2"] = float(b(c["a1"])[0].item())
+        edges = ops.node2edge_grouped([(c["xp"].view(c["B"], c["N"], D), c["pq"].view(c["B"], c["N"], D), c["H"], c["w2"],
+                                        c["b2"], False) for c in S])
+        for c, e in zip(S, edges):
+            c["edges"] = e.view(c["R"], D)
+        stage(lambda c: c.update(z1=gb.add(c["edges"], W(c["i"][0]), new(c["R"], 128), tB=True, bias=b(c["i"][0]),
+                                           relu=True)))
+        stage(lambda c: c.update(z=gb.add(c["z1"], W(c["i"][1]), new(c["R"], D), tB=True, bias=b(c["i"][1]))))
+
+        def dh1_stage(c):
+            c["dh1"] = new(c["R"], 256)        # hidden layers of MLP_distribution | MLP_factor
+            gb.add(c["z"], W(c["d"][0]), c["dh1"][:, :128], tB=True, bias=b(c["d"][0]), relu=True)
+            gb.add(c["z"], W(c["f"][0]), c["dh1"][:, 128:], tB=True, bias=b(c["f"][0]), relu=True)
+        stage(dh1_stage)
+
+        def lgf_stage(c):
+            K = c["K"]
+            c["lgf"] = new(c["R"], _LGF_LD)    # columns 0..K-1 logits, column K the factor pre-activation
+            gb.add(c["dh1"][:, :128], W(c["d"][1]), c["lgf"][:, :K], tB=True, bias=b(c["d"][1]))
+            gb.add(c["dh1"][:, 128:], W(c["f"][1]), c["lgf"][:, K:K + 1], tB=True, bias=b(c["f"][1]))
+        stage(lgf_stage)
+        for c in S:
+            c["ef"] = new(c["R"], c["K"])
             with torch.cuda.device(dev):
-                check(load().gn_gumbel_bwd_f32(_p(dist2), _p(lgf), _p(def_), _p(gd), _p(dlgf), B * E, K, 32, _TAU,
-                                               stream_handle()), "gn_gumbel_bwd_f32")
-            dd1 = gemm(dlgf, Wd1, mask=dh1)                            # (BE,256)
-            gWd1 = gemm(dlgf, dh1, transA=True)                        # (32,256)
-            gbd1 = colsum(dlgf)
-            grads[d1.weight] = gWd1[:K, :128].contiguous()
-            grads[f1.weight] = gWd1[K:K + 1, 128:].contiguous()
-            grads[d1.bias] = gbd1[:K].contiguous()
-            grads[f1.bias] = gbd1[K:K + 1].contiguous()
-            dz = gemm(dd1, Wd0)                                        # (BE,64)
-            gWd0 = gemm(dd1, z, transA=True)                           # (256,64)
-            gbd0 = colsum(dd1)
-            grads[d0.weight], grads[f0.weight] = gWd0[:128].contiguous(), gWd0[128:].contiguous()
-            grads[d0.bias], grads[f0.bias] = gbd0[:128].contiguous(), gbd0[128:].contiguous()
-            dz1 = gemm(dz, i1.weight.detach(), mask=z1)                # (BE,128)
-            grads[i1.weight] = gemm(dz, z1, transA=True)
-            grads[i1.bias] = colsum(dz)
-            dedges = gemm(dz1, i0.weight.detach())                     # (BE,64)
-            grads[i0.weight] = gemm(dz1, edges2, transA=True)
-            grads[i0.bias] = colsum(dz1)
-            # node -> edge pooling
-            dxp = torch.zeros((B * N, D), dtype=h.dtype, device=dev)
-            dpq = torch.zeros((B * N, D), dtype=h.dtype, device=dev)
-            dw2 = torch.zeros(32, dtype=h.dtype, device=dev)
-            db2 = torch.zeros(1, dtype=h.dtype, device=dev)
+                check(load().gn_gumbel_ef_f32(_p(c["dist"]), _p(c["lgf"]), _p(c["ef"]), c["R"], c["K"], _LGF_LD,
+                                              stream_handle()), "gn_gumbel_ef_f32")
+            c["def"] = c["pool"].take(c["R"], c["K"])
+            c["dx"] = None
+
+        live = [c for c in S if c["g_y"] is not None]
+        if live:
+            S_all, S = S, live
+            eos = ops.agg_gather_grouped([(c["x"], c["H"], False) for c in S])
+            for c, eo in zip(S, eos):
+                c["eo"], c["eo2"] = eo, eo.view(c["R"], D)
+            stage(lambda c: c.update(Hc=gb.add(c["eo2"], c["tw"]["W1cat"], new(c["R"], c["K"] * _HID), tB=True,
+                                               bias=c["tw"]["b1cat"], relu=True)))
+            feats = ops.agg_mlp_grouped([(c["eo"], c["ef"].view(c["B"], c["E"], c["K"]), c["agg"]._packed(), c["K"])
+                                         for c in S])
+            aggs = ops.agg_scatter_grouped([(f, c["H"], c["x"], False) for f, c in zip(feats, S)])
+            for c, a in zip(S, aggs):
+                c["agg2"] = a.view(c["B"] * c["N"], 2 * D)      # cat(H^T feat, ori) / N
+            stage(lambda c: c.update(y1=gb.add(c["agg2"], W(c["e0"]), new(c["B"] * c["N"], 128), tB=True,
+                                               bias=b(c["e0"]), relu=True)))
+            # ---------------- back through MLP(edge2node) ----------------
+            stage(lambda c: c.update(dy1=gb.add(c["g_y"], W(c["e1"]), new(c["B"] * c["N"], 128), mask=c["y1"])))
+
+            def dagg_stage(c):
+                inv = 1.0 / c["N"]
+                c["da"] = gb.add(c["dy1"], W(c["e0"])[:, :D], new(c["B"] * c["N"], D), alpha=inv)   # d(H^T feat)
+                c["dx"] = gb.add(c["dy1"], W(c["e0"])[:, D:], new(c["B"] * c["N"], D), alpha=inv)   # ori half of the cat
+            stage(dagg_stage)
+            dfeats = ops.agg_gather_grouped([(c["da"].view(c["B"], c["N"], D), c["H"], False) for c in S])   # adjoint of H^T feat
+            for c, df in zip(S, dfeats):
+                c["dfeat"] = df.view(c["R"], D)
+            stage(lambda c: c.update(T=gb.add(c["dfeat"], c["tw"]["W2cat"], new(c["R"], c["K"] * _HID))))
+            for c in S:
+                with torch.cuda.device(dev):
+                    check(load().gn_typed_bwd_f32(_p(c["T"]), _p(c["Hc"]), _p(c["ef"]), _p(c["dfeat"]), _p(c["tw"]["b2mat"]),
+                                                  _p(c["def"]), c["R"], c["K"], _HID, stream_handle()), "gn_typed_bwd_f32")
+            stage(lambda c: c.update(deo=gb.add(c["T"], c["tw"]["W1cat"], new(c["R"], D))))
+            # eo = H ori  ->  d ori += H^T d eo  (the scatter kernel with divisor 1; its ori half is unused)
+            scs = ops.agg_scatter_grouped([(c["deo"].view(c["B"], c["E"], D), c["H"], c["x"], False) for c in S], 1.0)
+            for c, sc in zip(S, scs):
+                axpby(c["dx"], sc.view(c["B"] * c["N"], 2 * D)[:, :D], 1.0, 1.0)
+
+            def e2n_weight_grads(c):
+                K, pool = c["K"], c["pool"]
+                for lin, dY, X in ((c["e1"], c["g_y"], c["y1"]), (c["e0"], c["dy1"], c["agg2"])):
+                    grads[lin.weight] = gb.add(dY, X, pool.take(*lin.weight.shape), tA=True, accum=True,
+                                               colsum=grads.setdefault(lin.bias, pool.take(*lin.bias.shape)))
+                gW1 = gb.add(c["T"], c["eo2"], pool.take(K * _HID, D), tA=True, accum=True,
+                             colsum=c.setdefault("gb1", pool.take(K * _HID)))
+                gb2 = gb.add(c["ef"], c["dfeat"], pool.take(K, D), tA=True, accum=True)
+                for k, m in enumerate(c["agg"].agg_mlp):
+                    l0, l1 = m.layers
+                    grads[l0.weight], grads[l0.bias] = gW1[k * _HID:(k + 1) * _HID], c["gb1"][k * _HID:(k + 1) * _HID]
+                    grads[l1.bias] = gb2[k]
+                    # dW2_k = sum_r ef[r,k] dfeat[r] (x) h_k[r]
+                    grads[l1.weight] = gb.add(c["dfeat"], c["Hc"][:, k * _HID:(k + 1) * _HID], pool.take(D, _HID), tA=True,
+                                              accum=True, rs=c["ef"][:, k])
+            stage(e2n_weight_grads)
+            S = S_all
+
+        # ---------------- back through the edge MLP + Gumbel softmax ----------------
+        for c in S:
+            c["dlgf"] = new(c["R"], _LGF_LD)
             with torch.cuda.device(dev):
-                check(load().gn_node2edge_bwd_f32(_p(xp), _p(pq), _p(H), _p(w2), b2, _p(dedges), _p(dxp), _p(dpq), _p(dw2),
-                                                  _p(db2), B, N, E, stream_handle()), "gn_node2edge_bwd_f32")
-            grads[a1.weight] = dw2.view(1, 32)
-            grads[a1.bias] = db2
-            gemm(dpq, Wpq, out=dxp, beta=1.0)                          # pq = Wpq x' + bpq
-            gWpq = gemm(dpq, xp, transA=True)                          # (64,64)
-            gbpq = colsum(dpq)
-            grads[a0.weight] = torch.cat((gWpq[:32], gWpq[32:]), dim=1).contiguous()   # back to the (32,128) layout
-            grads[a0.bias] = gbpq[:32].contiguous()
-            dx1 = gemm(dxp, s1.weight.detach(), mask=x1)               # (BN,256)
-            grads[s1.weight] = gemm(dxp, x1, transA=True)
-            grads[s1.bias] = colsum(dxp)
-            gemm(dx1, s0.weight.detach(), out=dh, beta=1.0)
-            grads[s0.weight] = gemm(dx1, h2, transA=True)
-            grads[s0.bias] = colsum(dx1)
-    return dh.view(B, N, D), grads
+                check(load().gn_gumbel_bwd_f32(_p(c["dist"]), _p(c["lgf"]), _p(c["def"]), _p(c["g_d"]), _p(c["dlgf"]),
+                                               c["R"], c["K"], _LGF_LD, _TAU, stream_handle()), "gn_gumbel_bwd_f32")
+
+        def dd1_stage(c):
+            K = c["K"]
+            c["dd1"] = new(c["R"], 256)
+            gb.add(c["dlgf"][:, :K], W(c["d"][1]), c["dd1"][:, :128], mask=c["dh1"][:, :128])
+            gb.add(c["dlgf"][:, K:K + 1], W(c["f"][1]), c["dd1"][:, 128:], mask=c["dh1"][:, 128:])
+        stage(dd1_stage)
+
+        def dz_stage(c):
+            c["dz"] = gb.add(c["dd1"][:, :128], W(c["d"][0]), new(c["R"], D))
+        stage(dz_stage)
+        stage(lambda c: gb.add(c["dd1"][:, 128:], W(c["f"][0]), c["dz"], beta=1.0))
+        stage(lambda c: c.update(dz1=gb.add(c["dz"], W(c["i"][1]), new(c["R"], 128), mask=c["z1"])))
+        stage(lambda c: c.update(dedges=gb.add(c["dz1"], W(c["i"][0]), new(c["R"], D))))
+        # ---------------- back through the attention-weighted pooling ----------------
+        for c in S:
+            pool, BN = c["pool"], c["B"] * c["N"]
+            c["dxp"], c["dpq"] = pool.take(BN, D), pool.take(BN, D)
+            grads[c["a1"].weight], grads[c["a1"].bias] = pool.take(1, 32), pool.take(1)
+            with torch.cuda.device(dev):
+                check(load().gn_node2edge_bwd_f32(_p(c["xp"]), _p(c["pq"]), _p(c["Hexp"]), _p(c["w2"]), c["b2"],
+                                                  _p(c["dedges"]), _p(c["dxp"]), _p(c["dpq"]), _p(grads[c["a1"].weight]),
+                                                  _p(grads[c["a1"].bias]), c["B"], c["N"], c["E"], stream_handle()),
+                      "gn_node2edge_bwd_f32")
+        stage(lambda c: gb.add(c["dpq"][:, :32], W(c["a0"])[:, :D], c["dxp"], beta=1.0))
+        stage(lambda c: gb.add(c["dpq"][:, 32:], W(c["a0"])[:, D:], c["dxp"], beta=1.0))
+        stage(lambda c: c.update(dx1=gb.add(c["dxp"], W(c["s1"]), new(c["B"] * c["N"], 256), mask=c["x1"])))
+
+        def dx_stage(c):
+            if c["dx"] is None:
+                c["dx"] = gb.add(c["dx1"], W(c["s0"]), new(c["B"] * c["N"], D))
+            else:
+                gb.add(c["dx1"], W(c["s0"]), c["dx"], beta=1.0)
+        stage(dx_stage)
+
+        def n2e_weight_grads(c):
+            K, pool = c["K"], c["pool"]
+
+            def wgrad(lin, dY, X):
+                grads[lin.weight] = gb.add(dY, X, pool.take(*lin.weight.shape), tA=True, accum=True,
+                                           colsum=grads.setdefault(lin.bias, pool.take(*lin.bias.shape)))
+            wgrad(c["d"][1], c["dlgf"][:, :K], c["dh1"][:, :128])
+            wgrad(c["f"][1], c["dlgf"][:, K:K + 1], c["dh1"][:, 128:])
+            wgrad(c["d"][0], c["dd1"][:, :128], c["z"])
+            wgrad(c["f"][0], c["dd1"][:, 128:], c["z"])
+            wgrad(c["i"][1], c["dz"], c["z1"])
+            wgrad(c["i"][0], c["dz1"], c["edges"])
+            ga0 = pool.take(32, 2 * D)                               # the (32,128) layout of attention layer 0
+            gb.add(c["dpq"][:, :32], c["xp"], ga0[:, :D], tA=True, accum=True,
+                   colsum=grads.setdefault(c["a0"].bias, pool.take(32)))
+            gb.add(c["dpq"][:, 32:], c["xp"], ga0[:, D:], tA=True, accum=True)
+            grads[c["a0"].weight] = ga0
+            wgrad(c["s1"], c["dxp"], c["x1"])
+            wgrad(c["s0"], c["dx1"], c["x2"])
+        stage(n2e_weight_grads)
+    return [c["dx"].view(c["B"], c["N"], D) for c in S]
+
+
+def modules_backward(traces: Sequence[ModuleTrace], g_nfs: Sequence[Optional[Tensor]],
+                     g_facs: Sequence[Optional[Tensor]]) -> Tuple[List[Tensor], Dict[nn.Parameter, Tensor]]:
+    """Gradients of (node_feat, factors) of several modules (same nmp_layers) w.r.t. their h_states and
+    parameters: the rounds walked backwards, each round grouped over the modules."""
+    L = traces[0].mod.nmp_layers - 1
+    grads: Dict[nn.Parameter, Tensor] = {}
+    g_ys = list(g_nfs)
+    for j in range(L, -1, -1):
+        g_ds = list(g_facs) if j == 0 else [None] * len(traces)
+        g_ys = round_backward(traces, j, g_ys, g_ds, grads)
+    return g_ys, grads
 
 
 class MSHGNNFunction(torch.autograd.Function):
-    """forward = the fused HIP path of the module; backward = `module_backward`."""
+    """Several modules on their inputs: forward = the grouped fused HIP path, backward = `modules_backward`.
+
+    apply(mods, Hs, noises, n_params_per_module, h_0..h_{n-1}, *params) -> (nf_0, fac_0, nf_1, fac_1, ...)."""
 
     @staticmethod
-    def forward(ctx, mod, H_or_none, noise_u, h, *params):
+    def forward(ctx, mods, Hs, noises, *tensors):
         from .MS_HGNN_batch import run_message_passing
+        n = len(mods)
+        hs, params = tensors[:n], tensors[n:]
+        traces = [ModuleTrace(m, h.detach(), H) for m, h, H in zip(mods, hs, Hs)]
         with torch.no_grad():
-            (node_feat, factors), = run_message_passing([mod], [h.detach()], [H_or_none], [noise_u], [None])
-        ctx.mod = mod
-        ctx.pairwise = H_or_none is None
-        ctx.params = params
-        ctx.save_for_backward(h.detach(), factors, *( [] if H_or_none is None else [H_or_none] ))
-        return node_feat, factors
+            res = run_message_passing(list(mods), [t.xs[0] for t in traces], list(Hs), list(noises), [None] * n,
+                                      traces=traces)
+        ctx.traces, ctx.params, ctx.n = traces, params, n
+        out = []
+        for nf, fac in res:
+            out += [nf, fac]
+        return tuple(out)
 
     @staticmethod
-    def backward(ctx, g_nf, g_fac):
-        saved = ctx.saved_tensors
-        h, factors = saved[0], saved[1]
-        B, N = h.shape[0], h.shape[1]
-        H = pairwise_incidence(B, N, h.device, h.dtype) if ctx.pairwise else saved[2]
-        g_nf = None if g_nf is None else g_nf.contiguous()
-        g_fac = None if g_fac is None else g_fac.contiguous()
-        dh, grads = module_backward(ctx.mod, h, H, factors, g_nf, g_fac)
-        return (None, None, None, dh) + tuple(grads.get(p) for p in ctx.params)
+    def backward(ctx, *gs):
+        n = ctx.n
+        g_nfs = [None if g is None else g.contiguous() for g in gs[0::2]]
+        g_facs = [None if g is None else g.contiguous() for g in gs[1::2]]
+        # a module none of whose outputs is used downstream contributes nothing
+        live = [i for i in range(n) if g_nfs[i] is not None or g_facs[i] is not None]
+        dhs: List[Optional[Tensor]] = [None] * n
+        grads: Dict[nn.Parameter, Tensor] = {}
+        if live:
+            d, grads = modules_backward([ctx.traces[i] for i in live], [g_nfs[i] for i in live],
+                                        [g_facs[i] for i in live])
+            for i, dh in zip(live, d):
+                dhs[i] = dh
+        return (None, None, None) + tuple(dhs) + tuple(grads.get(p) for p in ctx.params)

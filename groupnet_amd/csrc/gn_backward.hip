@@ -3,10 +3,12 @@
 // The forward is a handful of fused matrix-core kernels; the backward is deliberately built from a few
 // GENERIC blocks, correctness first (train_hyper_nba.py:116 back-propagates through these modules, but
 // training throughput is not the path's headline):
-//   gn_gemm_f32            C = beta*C + op(A) op(B) (+ bias) (relu) (masked by another tensor's sign);
-//                          LDS-tiled 64x64x16 VALU SGEMM with optional split-K (atomic) — used for the
-//                          re-computation of hidden activations, for input gradients dX = dY W and for
-//                          weight gradients dW = dY^T X (K = rows, split over workgroups);
+//   gn_gemm[_grouped]_f32  C = beta*C + op(A) op(B) (+ bias) (relu) (masked by another tensor's sign), many
+//                          problems per launch; LDS-staged 128x64x32 tiles on the fp32 matrix cores with
+//                          optional split-K (atomic) — used for the re-computation of hidden activations,
+//                          for input gradients dX = dY W and for weight gradients dW = dY^T X (K = rows,
+//                          split over workgroups, bias gradient as a side output);
+//   gn_typed_bwd_f32       the per-type scalings / dot products of the typed aggregation;
 //   gn_colsum_f32          bias gradients db = sum_rows dY;
 //   gn_typed_scale/dot     the per-row, per-type scalings of the typed aggregation;
 //   gn_gumbel_bwd_f32      back through fac * softmax((logits + g) / tau) and the sigmoid;
@@ -18,87 +20,137 @@
 namespace {
 
 constexpr int kB = 256;
-constexpr int TM = 64, TN = 64, TK = 16;
+constexpr int BM = 128, BN = 64, BK = 32;   // workgroup tile; each of the 4 waves owns 32 x 64 of it
+constexpr int kMaxDescs = 16;
 
-// element (r, c) of op(X): X is (rows x cols) row-major with leading dimension ld; trans reads X^T
-__device__ __forceinline__ float at(const float* __restrict__ X, int ld, int trans, int r, int c) {
-  return trans ? X[(size_t)c * ld + r] : X[(size_t)r * ld + c];
-}
+typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(kB) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                  float* __restrict__ C, int M, int N, int K, int lda, int ldb,
-                                                  int ldc, int transA, int transB, const float* __restrict__ bias,
-                                                  const float* __restrict__ mask, int ldmask, int relu, float alpha,
-                                                  float beta, int kchunk) {
-  __shared__ float As[TK][TM + 4];
-  __shared__ float Bs[TK][TN + 4];
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  const int k_lo = blockIdx.z * kchunk, k_hi = min(K, k_lo + kchunk);
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 x 4 outputs each
-  float acc[4][4];
+// one GEMM problem of a grouped launch (by value in the kernarg segment)
+struct GemmDesc {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* mask;
+  const float* rs;     // optional scale of A's STORED rows: A_eff[r][:] = rs[r*rs_ld] * A[r][:]
+  float* colsum;       // transA only: colsum[m] += sum_k A_eff[k][m]  (bias gradient next to dW = dY^T X)
+  int M, N, K, lda, ldb, ldc, ldmask, rs_ld;
+  int flags;
+  float alpha, beta;
+  int tile0, gn, gmn, kchunk;   // filled by the launcher
+};
+struct GemmTable {
+  GemmDesc d[kMaxDescs];
+  int n;
+};
+
+// C = beta*C + alpha*op(A)op(B) (+bias)(relu)(mask), or with GN_GEMM_ACCUM: C += alpha*op(A)op(B) by atomics
+// (K split over workgroups).  fp32 matrix cores (v_mfma_f32_32x32x2_f32), operands staged through LDS
+// k-major so that either storage order of A and B loads coalesced.
+__global__ __launch_bounds__(kB) void gemm_mfma_kernel(const GemmTable T) {
+  __shared__ float As[BK][BM + 4];
+  __shared__ float Bs[BK][BN + 4];
+  int g = 0;
+  for (int i = 1; i < T.n; ++i)
+    if ((int)blockIdx.x >= T.d[i].tile0) g = i;
+  g = gn_uniform(g);
+  const GemmDesc& D = T.d[g];
+  const int local = (int)blockIdx.x - D.tile0;
+  const int split = local / D.gmn, t = local - split * D.gmn;
+  const int tm = t / D.gn, tn = t - tm * D.gn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = D.M, N = D.N;
+  const int k_lo = split * D.kchunk, k_hi = min(D.K, k_lo + D.kchunk);
+  const bool transA = D.flags & GN_GEMM_TRANS_A, transB = D.flags & GN_GEMM_TRANS_B;
+  const float* __restrict__ A = D.A;
+  const float* __restrict__ Bm = D.B;
+  const float* __restrict__ rs = D.rs;
+  const int lda = D.lda, ldb = D.ldb, rs_ld = D.rs_ld;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  floatx16 acc0, acc1;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
-    for (int idx = threadIdx.x; idx < TK * TM; idx += kB) {
-      int kk, mm;
-      if (transA) {  // A stored K x M: consecutive m contiguous
-        kk = idx / TM;
-        mm = idx - kk * TM;
-      } else {       // A stored M x K: consecutive k contiguous
-        mm = idx / TK;
-        kk = idx - mm * TK;
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  const bool want_cs = D.colsum != nullptr && tn == 0 && transA;
+  float cs = 0.f;
+  for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
+    if (transA) {   // stored (K x M): m contiguous
+#pragma unroll 4
+      for (int idx = tid; idx < BK * BM; idx += kB) {
+        const int kk = idx / BM, mm = idx - kk * BM;
+        const int m = m0 + mm, k = k0 + kk;
+        float v = 0.f;
+        if (m < M && k < k_hi) {
+          v = A[(size_t)k * lda + m];
+          if (rs) v *= rs[(size_t)k * rs_ld];
+        }
+        As[kk][mm] = v;
       }
-      const int m = m0 + mm, k = k0 + kk;
-      As[kk][mm] = (m < M && k < k_hi) ? at(A, lda, transA, m, k) : 0.f;
+    } else {        // stored (M x K): k contiguous
+#pragma unroll 4
+      for (int idx = tid; idx < BK * BM; idx += kB) {
+        const int mm = idx / BK, kk = idx - mm * BK;
+        const int m = m0 + mm, k = k0 + kk;
+        float v = 0.f;
+        if (m < M && k < k_hi) {
+          v = A[(size_t)m * lda + k];
+          if (rs) v *= rs[(size_t)m * rs_ld];
+        }
+        As[kk][mm] = v;
+      }
     }
-    for (int idx = threadIdx.x; idx < TK * TN; idx += kB) {
-      int kk, nn;
-      if (transB) {  // B stored N x K
-        nn = idx / TK;
-        kk = idx - nn * TK;
-      } else {       // B stored K x N
-        kk = idx / TN;
-        nn = idx - kk * TN;
+    if (transB) {   // stored (N x K): k contiguous
+#pragma unroll 4
+      for (int idx = tid; idx < BK * BN; idx += kB) {
+        const int nn = idx / BK, kk = idx - nn * BK;
+        const int n = n0 + nn, k = k0 + kk;
+        Bs[kk][nn] = (n < N && k < k_hi) ? Bm[(size_t)n * ldb + k] : 0.f;
       }
-      const int n = n0 + nn, k = k0 + kk;
-      Bs[kk][nn] = (n < N && k < k_hi) ? at(Bm, ldb, transB, k, n) : 0.f;
+    } else {        // stored (K x N): n contiguous
+#pragma unroll 4
+      for (int idx = tid; idx < BK * BN; idx += kB) {
+        const int kk = idx / BN, nn = idx - kk * BN;
+        const int n = n0 + nn, k = k0 + kk;
+        Bs[kk][nn] = (n < N && k < k_hi) ? Bm[(size_t)k * ldb + n] : 0.f;
+      }
     }
     __syncthreads();
+    if (want_cs && tid < BM) {
 #pragma unroll
-    for (int kk = 0; kk < TK; ++kk) {
-      float a[4], b[4];
+      for (int kk = 0; kk < BK; ++kk) cs += As[kk][tid];
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a = As[kk + hi][wave * 32 + l31];
+      const float b0 = Bs[kk + hi][l31], b1 = Bs[kk + hi][32 + l31];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
     }
     __syncthreads();
   }
-  const bool split = gridDim.z > 1;
+  if (want_cs && tid < BM && m0 + tid < M) atomicAdd(D.colsum + m0 + tid, cs);
+  const bool accum = D.flags & GN_GEMM_ACCUM, relu = D.flags & GN_GEMM_RELU;
+  const float alpha = D.alpha, beta = D.beta;
+  const float* __restrict__ bias = D.bias;
+  const float* __restrict__ mask = D.mask;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
-    if (m >= M) continue;
+  for (int half = 0; half < 2; ++half) {
+    const int n = n0 + half * 32 + l31;
+    if (n >= N) continue;
+    const float bn = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
-      if (n >= N) continue;
-      float* c = C + (size_t)m * ldc + n;
-      if (split) {  // partial sums of a K split: C was prepared (zeroed or holding beta*C) by the launcher
-        atomicAdd(c, alpha * acc[i][j]);
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (m >= M) continue;
+      float v = alpha * (half ? acc1[r] : acc0[r]);
+      float* c = D.C + (size_t)m * D.ldc + n;
+      if (accum) {
+        atomicAdd(c, v);
         continue;
       }
-      float v = alpha * acc[i][j];
-      if (bias) v += bias[n];
+      v += bn;
       if (beta != 0.f) v += beta * *c;
       if (relu) v = fmaxf(v, 0.f);
-      if (mask && !(mask[(size_t)m * ldmask + n] > 0.f)) v = 0.f;
+      if (mask && !(mask[(size_t)m * D.ldmask + n] > 0.f)) v = 0.f;
       *c = v;
     }
   }
@@ -302,6 +354,33 @@ __global__ __launch_bounds__(kB) void gumbel_ef_kernel(const float* __restrict__
   }
 }
 
+// Typed aggregation MLP, middle of its backward (one wave per edge row, all K types):
+//   T (rows, K*hid) = dfeat W2cat on entry; Hc (rows, K*hid) the hidden activations relu(W1_k eo + b1_k);
+//   def[r][k] = <T[r,k,:], Hc[r,k,:]> + <dfeat[r], b2[k]>      (= <dfeat, MLP_k(eo)>, the gradient of ef_k)
+//   T[r,k,:] <- ef[r][k] * T[r,k,:] where Hc > 0, else 0        (= the gradient of the pre-activation)
+__global__ __launch_bounds__(kB) void typed_bwd_kernel(float* __restrict__ T, const float* __restrict__ Hc,
+                                                       const float* __restrict__ ef, const float* __restrict__ dfeat,
+                                                       const float* __restrict__ b2, float* __restrict__ def,
+                                                       long long rows, int K, int hid) {
+  const int lane = threadIdx.x & 63;
+  for (long long r = (long long)blockIdx.x * (kB / 64) + (threadIdx.x >> 6); r < rows;
+       r += (long long)gridDim.x * (kB / 64)) {
+    const float g = dfeat[r * GN_FEAT + lane];
+    for (int k = 0; k < K; ++k) {
+      const size_t base = ((size_t)r * K + k) * hid;
+      const float e = ef[r * K + k];
+      float v = g * b2[k * GN_FEAT + lane];
+      for (int c = lane; c < hid; c += 64) {
+        const float t = T[base + c], h = Hc[base + c];
+        v = fmaf(t, h, v);
+        T[base + c] = h > 0.f ? e * t : 0.f;
+      }
+      v = gn_wave_sum(v);
+      if (lane == 0) def[r * K + k] = v;
+    }
+  }
+}
+
 inline int cap_grid(long long items, int per_block, int cap = 4096) {
   long long g = (items + per_block - 1) / per_block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -309,33 +388,72 @@ inline int cap_grid(long long items, int per_block, int cap = 4096) {
 
 }  // namespace
 
+static int gemm_validate(const gn_gemm_desc_t& d) {
+  if (d.A == nullptr || d.B == nullptr || d.C == nullptr) return GN_ERR_NULL;
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.ldc < d.N) return GN_ERR_SHAPE;
+  const bool tA = d.flags & GN_GEMM_TRANS_A, tB = d.flags & GN_GEMM_TRANS_B;
+  if (d.lda < (tA ? d.M : d.K) || d.ldb < (tB ? d.K : d.N)) return GN_ERR_SHAPE;
+  if (d.mask && d.ldmask < d.N) return GN_ERR_SHAPE;
+  if (d.colsum && !tA) return GN_ERR_SHAPE;
+  if ((d.flags & GN_GEMM_ACCUM) && (d.bias || d.mask || (d.flags & GN_GEMM_RELU))) return GN_ERR_SHAPE;
+  return GN_OK;
+}
+
+extern "C" int gn_gemm_grouped_f32(const gn_gemm_desc_t* descs, int n, gn_stream_t stream) {
+  GN_REQUIRE_PTR(descs);
+  if (n < 1) return GN_ERR_SHAPE;
+  for (int i = 0; i < n; ++i) {
+    const int rc = gemm_validate(descs[i]);
+    if (rc != GN_OK) return rc;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  for (int base = 0; base < n; base += kMaxDescs) {
+    GemmTable T;
+    T.n = n - base < kMaxDescs ? n - base : kMaxDescs;
+    long long tiles = 0;
+    for (int i = 0; i < T.n; ++i) {
+      const gn_gemm_desc_t& d = descs[base + i];
+      GemmDesc& g = T.d[i];
+      g.A = d.A; g.B = d.B; g.C = d.C; g.bias = d.bias; g.mask = d.mask; g.rs = d.rs; g.colsum = d.colsum;
+      g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc; g.ldmask = d.ldmask;
+      g.rs_ld = d.rs_ld; g.flags = d.flags; g.alpha = d.alpha; g.beta = d.beta;
+      const int gm = (d.M + BM - 1) / BM, gn = (d.N + BN - 1) / BN;
+      int splits = 1;
+      if (d.flags & GN_GEMM_ACCUM) {   // long K over few tiles: split K, partial sums by atomics
+        splits = (768 + gm * gn - 1) / (gm * gn);
+        const int max_splits = (d.K + 255) / 256;
+        splits = splits > max_splits ? max_splits : splits;
+      }
+      int kchunk = ((d.K + splits - 1) / splits + BK - 1) / BK * BK;
+      splits = (d.K + kchunk - 1) / kchunk;
+      g.tile0 = (int)tiles; g.gn = gn; g.gmn = gm * gn; g.kchunk = kchunk;
+      tiles += (long long)gm * gn * splits;
+      if (tiles > 0x7fffffffLL) return GN_ERR_SHAPE;
+    }
+    hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)tiles), dim3(kB), 0, s, T);
+  }
+  return gn_check_launch();
+}
+
 extern "C" int gn_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                            int transA, int transB, const float* bias, const float* mask, int ldmask, int relu,
                            float alpha, float beta, gn_stream_t stream) {
-  GN_REQUIRE_PTR(A);
-  GN_REQUIRE_PTR(B);
-  GN_REQUIRE_PTR(C);
-  if (M <= 0 || N <= 0 || K <= 0 || ldc < N) return GN_ERR_SHAPE;
-  if (lda < (transA ? M : K) || ldb < (transB ? K : N)) return GN_ERR_SHAPE;
-  hipStream_t s = (hipStream_t)stream;
-  const int gm = (M + TM - 1) / TM, gn = (N + TN - 1) / TN;
-  // few output tiles and a long K (weight gradients): split K over workgroups, partial sums by atomics
-  int splits = 1;
-  if ((long long)gm * gn < 256 && K >= 4096 && !relu && !mask && !bias) {
-    splits = (int)((512 + (long long)gm * gn - 1) / ((long long)gm * gn));
-    const int max_splits = (K + 255) / 256;
-    splits = splits > max_splits ? max_splits : splits;
-  }
-  int kchunk = ((K + splits - 1) / splits + TK - 1) / TK * TK;
-  splits = (K + kchunk - 1) / kchunk;
-  if (splits > 1) {
-    // C <- beta*C (or 0) first; the workgroups of the split then add their partial sums atomically
+  gn_gemm_desc_t d{};
+  d.A = A; d.B = B; d.C = C; d.bias = bias; d.mask = mask;
+  d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.ldmask = ldmask;
+  d.flags = (transA ? GN_GEMM_TRANS_A : 0) | (transB ? GN_GEMM_TRANS_B : 0) | (relu ? GN_GEMM_RELU : 0);
+  d.alpha = alpha; d.beta = beta;
+  const int rc = gemm_validate(d);
+  if (rc != GN_OK) return rc;
+  const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if (tiles < 128 && K >= 4096 && !relu && !mask && !bias) {
+    // weight-gradient shape: C <- beta*C first, then the K split adds its partial sums atomically
     const long long total = (long long)M * N;
-    hipLaunchKernelGGL(scale_kernel, dim3(cap_grid(total, kB)), dim3(kB), 0, s, C, total, N, ldc, beta);
+    hipLaunchKernelGGL(scale_kernel, dim3(cap_grid(total, kB)), dim3(kB), 0, (hipStream_t)stream, C, total, N, ldc, beta);
+    d.flags |= GN_GEMM_ACCUM;
+    d.beta = 0.f;
   }
-  hipLaunchKernelGGL(gemm_kernel, dim3(gn, gm, splits), dim3(kB), 0, s, A, B, C, M, N, K, lda, ldb, ldc, transA, transB,
-                     bias, mask, ldmask, relu, alpha, beta, kchunk);
-  return gn_check_launch();
+  return gn_gemm_grouped_f32(&d, 1, stream);
 }
 
 extern "C" int gn_colsum_f32(const float* X, float* out, int rows, int cols, int ld, gn_stream_t stream) {
@@ -417,5 +535,16 @@ extern "C" int gn_gumbel_ef_f32(const float* dist, const float* lgf, float* ef, 
   if (rows <= 0 || K < 1 || ldl <= K) return GN_ERR_SHAPE;
   hipLaunchKernelGGL(gumbel_ef_kernel, dim3(cap_grid(rows * K, kB)), dim3(kB), 0, (hipStream_t)stream, dist, lgf, ef,
                      rows, K, ldl);
+  return gn_check_launch();
+}
+
+extern "C" int gn_typed_bwd_f32(float* T, const float* Hc, const float* ef, const float* dfeat, const float* b2,
+                                float* def, long long rows, int K, int hid, gn_stream_t stream) {
+  const void* ptrs[] = {T, Hc, ef, dfeat, b2, def};
+  for (const void* p : ptrs)
+    if (p == nullptr) return GN_ERR_NULL;
+  if (rows <= 0 || K < 1 || hid < 64 || hid % 64) return GN_ERR_SHAPE;
+  hipLaunchKernelGGL(typed_bwd_kernel, dim3(cap_grid(rows, kB / 64, 8192)), dim3(kB), 0, (hipStream_t)stream, T, Hc, ef,
+                     dfeat, b2, def, rows, K, hid);
   return gn_check_launch();
 }

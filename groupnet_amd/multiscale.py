@@ -70,19 +70,22 @@ class MultiScaleHGNN(nn.Module):
         S = len(self.hyper_scales)
         nmp = self.interaction.nmp_layers
         if _needs_grad(self, f):
-            # training: module by module through autograd (fused forward, HIP backward each); the concat
-            # is an ordinary differentiable torch.cat
+            # training: ONE autograd node for the 1+S modules (grouped fused forward, grouped HIP backward);
+            # the concat is an ordinary differentiable torch.cat
+            from .backward import MSHGNNFunction
             if S:
                 _, Hs, new_H = ops.affinity_topk(f.detach(), self.hyper_scales, want_corr=False, want_H_cat=True)
             else:
                 Hs, new_H = [], None
             if advance:
                 ops.counter_add(advance[0], advance[1])
-            nz = noise_u if noise_u is not None else [None] * (1 + S)
-            feats = [f, self.interaction(f, noise_u=nz[0])[0]]
-            for m, H, u in zip(self.interaction_hyper, Hs, nz[1:]):
-                feats.append(m(f, None, noise_u=u, H=H)[0])
-            return torch.cat(feats, dim=-1), new_H
+            mods = (self.interaction, *self.interaction_hyper)
+            nz = tuple(noise_u) if noise_u is not None else (None,) * (1 + S)
+            if len(nz) != 1 + S:
+                raise ValueError(f"noise_u: need {1 + S} entries (pairwise + one per scale)")
+            params = [p for m in mods for p in m.parameters()]
+            res = MSHGNNFunction.apply(mods, (None, *Hs), nz, *([f] * (1 + S)), *params)
+            return torch.cat([f, *res[0::2]], dim=-1), new_H
         if noise_u is None:
             # reference order: every draw of the pairwise module first, then scale by scale
             from .MS_HGNN_batch import _draw_uniform

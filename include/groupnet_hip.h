@@ -294,6 +294,28 @@ int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, 
  *   gdist = d dist or NULL -> dlgf (rows,ldl): columns 0..K-1 = d logits, column K = d f, rest 0.
  * gn_node2edge_bwd_f32: back through gn_node2edge_f32 for an explicit H (B,E,N): given dedges (B,E,64)
  *   ADDS into dxp (B,N,64), dpq (B,N,64), dw2 (32), db2 (1) (atomics; zero them first). */
+/* Grouped form: n independent problems in one launch (all types of the typed aggregation MLP, all modules
+ * of a multiscale block).  rs (optional) scales A's STORED rows: A_eff[r][:] = rs[r*rs_ld] * A[r][:];
+ * colsum (optional, GN_GEMM_TRANS_A only) receives colsum[m] += sum_k A_eff[k][m] — the bias gradient next
+ * to dW = dY^T X.  GN_GEMM_ACCUM: C += alpha*op(A)op(B) by atomic adds with K split over workgroups (C must
+ * hold zeros / the running sum; no bias, relu, mask, beta). */
+#define GN_GEMM_TRANS_A 1
+#define GN_GEMM_TRANS_B 2
+#define GN_GEMM_RELU 4
+#define GN_GEMM_ACCUM 8
+typedef struct {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* mask;
+  const float* rs;
+  float* colsum;
+  int M, N, K, lda, ldb, ldc, ldmask, rs_ld;
+  int flags;
+  float alpha, beta;
+} gn_gemm_desc_t;
+int gn_gemm_grouped_f32(const gn_gemm_desc_t* descs, int n, gn_stream_t stream);
 int gn_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                 int transA, int transB, const float* bias, const float* mask, int ldmask, int relu,
                 float alpha, float beta, gn_stream_t stream);
@@ -305,6 +327,11 @@ int gn_axpby2d_f32(float* out, int ldo, const float* a, int lda, long long rows,
  * pre-activation (column K of lgf (rows, ldl)). */
 int gn_gumbel_ef_f32(const float* dist, const float* lgf, float* ef, long long rows, int K, int ldl,
                      gn_stream_t stream);
+/* Middle of the typed aggregation MLP's backward (model/MS_HGNN_batch.py:264-265), all K types of a row at
+ * once: T (rows, K*hid) holds dfeat W2cat, Hc (rows, K*hid) the hidden activations; writes
+ * def[r][k] = <T[r,k,:], Hc[r,k,:]> + <dfeat[r], b2[k]> and T[r,k,:] <- ef[r][k] * T[r,k,:] * (Hc > 0). */
+int gn_typed_bwd_f32(float* T, const float* Hc, const float* ef, const float* dfeat, const float* b2, float* def,
+                     long long rows, int K, int hid, gn_stream_t stream);
 int gn_colsum_f32(const float* X, float* out, int rows, int cols, int ld, gn_stream_t stream);
 int gn_rowscale_f32(float* dst, const float* src, const float* s, long long rows, int cols, int lds, int off,
                     gn_stream_t stream);
