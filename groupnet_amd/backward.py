@@ -114,6 +114,23 @@ def pairwise_incidence(B: int, N: int, device, dtype=torch.float32) -> Tensor:
     return H[None].expand(B, -1, -1).contiguous()
 
 
+_pair_w_cache: Dict[tuple, Tensor] = {}
+
+
+def _pair_row_weights(B: int, N: int, device) -> Tensor:
+    """(B * N(N+1)/2) incidence weight of each unordered-pair row on its nodes: 2 on self-loops, else 1."""
+    key = (B, N, str(device))
+    w = _pair_w_cache.get(key)
+    if w is None:
+        i = torch.arange(N, device=device)
+        one = torch.ones(ops.pair_count(N), dtype=torch.float32, device=device)
+        one[i * N - (i * (i - 1)) // 2] = 2.0          # row of the pair (i, i)
+        w = _pair_w_cache[key] = one.repeat(B).contiguous()
+        if len(_pair_w_cache) > 16:
+            _pair_w_cache.pop(next(iter(_pair_w_cache)))
+    return w
+
+
 class _Pool:
     """Zero-initialised scratch handed out in slices: every accumulate-by-atomics target of a round comes
     from one fill instead of one fill each."""
@@ -185,18 +202,24 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
         mod, x = t.mod, t.xs[j]
         B, N, _ = x.shape
         Hx = t.H
-        if Hx is None and "_pair_H" not in t.__dict__:
-            t._pair_H = pairwise_incidence(B, N, x.device, x.dtype)
-        E = N * N if Hx is None else Hx.shape[1]
+        scene_fits = (4 * N * D + 64 + 16 * N) * 4 <= 150 * 1024     # gn_node2edge_bwd_f32's per-scene form
+        # The pairwise graph is symmetric: the ordered edges (i,j) and (j,i) pool the same feature and feed
+        # the same typed MLP, so (as in the forward) every per-edge stage runs on the N(N+1)/2 unordered
+        # pairs; only dist (its own Gumbel noise per ordered edge) stays ordered.
+        sym = Hx is None and scene_fits
+        if Hx is None and not sym:
+            Hx = t.__dict__.setdefault("_pair_H", None)
+            if Hx is None:
+                Hx = t._pair_H = pairwise_incidence(B, N, x.device, x.dtype)
+        E = ops.pair_count(N) if sym else Hx.shape[1]
         K = mod.edge_types
         (s0, s1), (a0, a1), st, agg, (e0, e1) = _round_layers(mod, j)
         npar = sum(p.numel() for m in (mod.node2edge_start_mlp[j], mod.attention_mlp[j], st, agg,
                                        nn.ModuleList([e0, e1])) for p in m.parameters())
-        S.append(dict(mod=mod, x=x, x2=x.reshape(B * N, D), H=Hx, Hexp=Hx if Hx is not None else t._pair_H, B=B, N=N,
-                      E=E, K=K, R=B * E, s0=s0, s1=s1, a0=a0, a1=a1, i=st.init_MLP.layers, d=st.MLP_distribution.layers,
+        S.append(dict(mod=mod, x=x, x2=x.reshape(B * N, D), H=Hx, sym=sym, B=B, N=N, E=E, K=K, R=B * E, s0=s0, s1=s1, a0=a0, a1=a1, i=st.init_MLP.layers, d=st.MLP_distribution.layers,
                       f=st.MLP_factor.layers, agg=agg, tw=_typed_weights(agg), e0=e0, e1=e1,
-                      dist=t.dists[j].reshape(B * E, K), g_y=None if g_y is None else g_y.reshape(B * N, -1).contiguous(),
-                      g_d=None if g_d is None else g_d.reshape(B * E, K).contiguous(),
+                      dist=t.dists[j].reshape(-1, K), g_y=None if g_y is None else g_y.reshape(B * N, -1).contiguous(),
+                      g_d=None if g_d is None else g_d.reshape(-1, K).contiguous(),
                       pool=_Pool(npar + 2 * B * N * D + B * E * (K + D) + 4096, x.device)))
     dev = S[0]["x"].device
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
@@ -220,10 +243,10 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
             gb.add(c["xp"], W(c["a0"])[:, D:], c["pq"][:, 32:], tB=True)
         stage(pq_stage)
         for c in S:
-            c["w2"] = W(c["a1"])[0].contiguous()
-            c["b2"] = float(b(c["a1"])[0].item())
+            pk = c["mod"]._packed_n2e(j)      # (w2, b2) as the forward cached them: no host sync here
+            c["w2"], c["b2"] = pk["w2"], pk["b2"]
         edges = ops.node2edge_grouped([(c["xp"].view(c["B"], c["N"], D), c["pq"].view(c["B"], c["N"], D), c["H"], c["w2"],
-                                        c["b2"], False) for c in S])
+                                        c["b2"], c["sym"]) for c in S])
         for c, e in zip(S, edges):
             c["edges"] = e.view(c["R"], D)
         stage(lambda c: c.update(z1=gb.add(c["edges"], W(c["i"][0]), new(c["R"], 128), tB=True, bias=b(c["i"][0]),
@@ -243,24 +266,28 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
             gb.add(c["dh1"][:, 128:], W(c["f"][1]), c["lgf"][:, K:K + 1], tB=True, bias=b(c["f"][1]))
         stage(lgf_stage)
         for c in S:
+            # ef per edge row; for pair rows ef_ij + ef_ji.  The forward's pair-form aggregation wants the
+            # self-loop rows doubled (H = 2 folded into ef): ef_fwd, used only to re-compute feat.
             c["ef"] = new(c["R"], c["K"])
+            c["ef_fwd"] = new(c["R"], c["K"]) if c["sym"] else c["ef"]
             with torch.cuda.device(dev):
-                check(load().gn_gumbel_ef_f32(_p(c["dist"]), _p(c["lgf"]), _p(c["ef"]), c["R"], c["K"], _LGF_LD,
-                                              stream_handle()), "gn_gumbel_ef_f32")
+                for dst, w in ((c["ef"], 1.0), (c["ef_fwd"], 2.0)) if c["sym"] else ((c["ef"], 1.0),):
+                    check(load().gn_gumbel_ef_f32(_p(c["dist"]), _p(c["lgf"]), _p(dst), c["R"], c["K"], _LGF_LD,
+                                                  c["N"] if c["sym"] else 0, w, stream_handle()), "gn_gumbel_ef_f32")
             c["def"] = c["pool"].take(c["R"], c["K"])
             c["dx"] = None
 
         live = [c for c in S if c["g_y"] is not None]
         if live:
             S_all, S = S, live
-            eos = ops.agg_gather_grouped([(c["x"], c["H"], False) for c in S])
+            eos = ops.agg_gather_grouped([(c["x"], c["H"], c["sym"]) for c in S])
             for c, eo in zip(S, eos):
                 c["eo"], c["eo2"] = eo, eo.view(c["R"], D)
             stage(lambda c: c.update(Hc=gb.add(c["eo2"], c["tw"]["W1cat"], new(c["R"], c["K"] * _HID), tB=True,
                                                bias=c["tw"]["b1cat"], relu=True)))
-            feats = ops.agg_mlp_grouped([(c["eo"], c["ef"].view(c["B"], c["E"], c["K"]), c["agg"]._packed(), c["K"])
+            feats = ops.agg_mlp_grouped([(c["eo"], c["ef_fwd"].view(c["B"], c["E"], c["K"]), c["agg"]._packed(), c["K"])
                                          for c in S])
-            aggs = ops.agg_scatter_grouped([(f, c["H"], c["x"], False) for f, c in zip(feats, S)])
+            aggs = ops.agg_scatter_grouped([(f, c["H"], c["x"], c["sym"]) for f, c in zip(feats, S)])
             for c, a in zip(S, aggs):
                 c["agg2"] = a.view(c["B"] * c["N"], 2 * D)      # cat(H^T feat, ori) / N
             stage(lambda c: c.update(y1=gb.add(c["agg2"], W(c["e0"]), new(c["B"] * c["N"], 128), tB=True,
@@ -273,7 +300,7 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                 c["da"] = gb.add(c["dy1"], W(c["e0"])[:, :D], new(c["B"] * c["N"], D), alpha=inv)   # d(H^T feat)
                 c["dx"] = gb.add(c["dy1"], W(c["e0"])[:, D:], new(c["B"] * c["N"], D), alpha=inv)   # ori half of the cat
             stage(dagg_stage)
-            dfeats = ops.agg_gather_grouped([(c["da"].view(c["B"], c["N"], D), c["H"], False) for c in S])   # adjoint of H^T feat
+            dfeats = ops.agg_gather_grouped([(c["da"].view(c["B"], c["N"], D), c["H"], c["sym"]) for c in S])   # adjoint of H^T feat
             for c, df in zip(S, dfeats):
                 c["dfeat"] = df.view(c["R"], D)
             stage(lambda c: c.update(T=gb.add(c["dfeat"], c["tw"]["W2cat"], new(c["R"], c["K"] * _HID))))
@@ -281,9 +308,11 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                 with torch.cuda.device(dev):
                     check(load().gn_typed_bwd_f32(_p(c["T"]), _p(c["Hc"]), _p(c["ef"]), _p(c["dfeat"]), _p(c["tw"]["b2mat"]),
                                                   _p(c["def"]), c["R"], c["K"], _HID, stream_handle()), "gn_typed_bwd_f32")
-            stage(lambda c: c.update(deo=gb.add(c["T"], c["tw"]["W1cat"], new(c["R"], D))))
+            # (pair rows: the self-loop's eo = 2 ori, and the pair-form scatter below weighs every row once)
+            stage(lambda c: c.update(deo=gb.add(c["T"], c["tw"]["W1cat"], new(c["R"], D),
+                                                rs=_pair_row_weights(c["B"], c["N"], dev) if c["sym"] else None)))
             # eo = H ori  ->  d ori += H^T d eo  (the scatter kernel with divisor 1; its ori half is unused)
-            scs = ops.agg_scatter_grouped([(c["deo"].view(c["B"], c["E"], D), c["H"], c["x"], False) for c in S], 1.0)
+            scs = ops.agg_scatter_grouped([(c["deo"].view(c["B"], c["E"], D), c["H"], c["x"], c["sym"]) for c in S], 1.0)
             for c, sc in zip(S, scs):
                 axpby(c["dx"], sc.view(c["B"] * c["N"], 2 * D)[:, :D], 1.0, 1.0)
 
@@ -310,7 +339,8 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
             c["dlgf"] = new(c["R"], _LGF_LD)
             with torch.cuda.device(dev):
                 check(load().gn_gumbel_bwd_f32(_p(c["dist"]), _p(c["lgf"]), _p(c["def"]), _p(c["g_d"]), _p(c["dlgf"]),
-                                               c["R"], c["K"], _LGF_LD, _TAU, stream_handle()), "gn_gumbel_bwd_f32")
+                                               c["R"], c["K"], _LGF_LD, _TAU, c["N"] if c["sym"] else 0, stream_handle()),
+                      "gn_gumbel_bwd_f32")
 
         def dd1_stage(c):
             K = c["K"]
@@ -331,9 +361,10 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
             c["dxp"], c["dpq"] = pool.take(BN, D), pool.take(BN, D)
             grads[c["a1"].weight], grads[c["a1"].bias] = pool.take(1, 32), pool.take(1)
             with torch.cuda.device(dev):
-                check(load().gn_node2edge_bwd_f32(_p(c["xp"]), _p(c["pq"]), _p(c["Hexp"]), _p(c["w2"]), c["b2"],
+                check(load().gn_node2edge_bwd_f32(_p(c["xp"]), _p(c["pq"]), _p(c["H"]), _p(c["w2"]), c["b2"],
                                                   _p(c["dedges"]), _p(c["dxp"]), _p(c["dpq"]), _p(grads[c["a1"].weight]),
-                                                  _p(grads[c["a1"].bias]), c["B"], c["N"], c["E"], stream_handle()),
+                                                  _p(grads[c["a1"].bias]), c["B"], c["N"], c["E"], int(c["sym"]),
+                                                  stream_handle()),
                       "gn_node2edge_bwd_f32")
         stage(lambda c: gb.add(c["dpq"][:, :32], W(c["a0"])[:, :D], c["dxp"], beta=1.0))
         stage(lambda c: gb.add(c["dpq"][:, 32:], W(c["a0"])[:, D:], c["dxp"], beta=1.0))

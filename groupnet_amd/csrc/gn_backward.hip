@@ -44,24 +44,60 @@ struct GemmTable {
   int n;
 };
 
-// C = beta*C + alpha*op(A)op(B) (+bias)(relu)(mask), or with GN_GEMM_ACCUM: C += alpha*op(A)op(B) by atomics
-// (K split over workgroups).  fp32 matrix cores (v_mfma_f32_32x32x2_f32), operands staged through LDS
-// k-major so that either storage order of A and B loads coalesced.
-__global__ __launch_bounds__(kB) void gemm_mfma_kernel(const GemmTable T) {
-  __shared__ float As[BK][BM + 4];
-  __shared__ float Bs[BK][BN + 4];
-  int g = 0;
-  for (int i = 1; i < T.n; ++i)
-    if ((int)blockIdx.x >= T.d[i].tile0) g = i;
-  g = gn_uniform(g);
-  const GemmDesc& D = T.d[g];
+// Register images of the next k-chunk of A (BM x BK) and B (BK x BN): all loads of a chunk are issued back
+// to back with clamped addresses (no branches between them) and are in flight while the matrix cores work
+// on the previous chunk; out-of-range elements are zeroed afterwards.
+constexpr int kALoads = BM * BK / kB, kBLoads = BN * BK / kB;
+
+template <bool TRANS>   // TRANS: stored (K x M), m contiguous; else stored (M x K), k contiguous
+__device__ __forceinline__ void fetch_a(float (&va)[kALoads], const float* __restrict__ A, const float* __restrict__ rs,
+                                        int lda, int rs_ld, int M, int m0, int k0, int k_hi, int tid) {
+  unsigned ok = 0;
+  size_t srow[kALoads];
+#pragma unroll
+  for (int it = 0; it < kALoads; ++it) {
+    const int idx = tid + it * kB;
+    const int mm = TRANS ? idx % BM : idx / BK, kk = TRANS ? idx / BM : idx % BK;
+    const int m = m0 + mm, k = k0 + kk;
+    if (m < M && k < k_hi) ok |= 1u << it;
+    const int mc = min(m, M - 1), kc = min(k, k_hi - 1);
+    srow[it] = TRANS ? kc : mc;
+    va[it] = A[srow[it] * lda + (TRANS ? mc : kc)];
+  }
+  if (rs) {
+    float vs[kALoads];
+#pragma unroll
+    for (int it = 0; it < kALoads; ++it) vs[it] = rs[srow[it] * rs_ld];
+#pragma unroll
+    for (int it = 0; it < kALoads; ++it) va[it] *= vs[it];
+  }
+#pragma unroll
+  for (int it = 0; it < kALoads; ++it)
+    if (!(ok >> it & 1u)) va[it] = 0.f;
+}
+
+template <bool TRANS>   // TRANS: stored (N x K), k contiguous; else stored (K x N), n contiguous
+__device__ __forceinline__ void fetch_b(float (&vb)[kBLoads], const float* __restrict__ Bm, int ldb, int N, int n0,
+                                        int k0, int k_hi, int tid) {
+#pragma unroll
+  for (int it = 0; it < kBLoads; ++it) {
+    const int idx = tid + it * kB;
+    const int nn = TRANS ? idx / BK : idx % BN, kk = TRANS ? idx % BK : idx / BN;
+    const int n = n0 + nn, k = k0 + kk;
+    const int nc = min(n, N - 1), kc = min(k, k_hi - 1);
+    const float v = TRANS ? Bm[(size_t)nc * ldb + kc] : Bm[(size_t)kc * ldb + nc];
+    vb[it] = (n < N && k < k_hi) ? v : 0.f;
+  }
+}
+
+template <bool TA, bool TB>
+__device__ __forceinline__ void gemm_body(const GemmDesc& D, float (&As)[BK][BM + 4], float (&Bs)[BK][BN + 4]) {
   const int local = (int)blockIdx.x - D.tile0;
   const int split = local / D.gmn, t = local - split * D.gmn;
   const int tm = t / D.gn, tn = t - tm * D.gn;
   const int m0 = tm * BM, n0 = tn * BN;
   const int M = D.M, N = D.N;
   const int k_lo = split * D.kchunk, k_hi = min(D.K, k_lo + D.kchunk);
-  const bool transA = D.flags & GN_GEMM_TRANS_A, transB = D.flags & GN_GEMM_TRANS_B;
   const float* __restrict__ A = D.A;
   const float* __restrict__ Bm = D.B;
   const float* __restrict__ rs = D.rs;
@@ -70,50 +106,29 @@ __global__ __launch_bounds__(kB) void gemm_mfma_kernel(const GemmTable T) {
   floatx16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-  const bool want_cs = D.colsum != nullptr && tn == 0 && transA;
+  const bool want_cs = TA && D.colsum != nullptr && tn == 0;
   float cs = 0.f;
+  float va[kALoads], vb[kBLoads];
+  fetch_a<TA>(va, A, rs, lda, rs_ld, M, m0, k_lo, k_hi, tid);
+  fetch_b<TB>(vb, Bm, ldb, N, n0, k_lo, k_hi, tid);
   for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
-    if (transA) {   // stored (K x M): m contiguous
-#pragma unroll 4
-      for (int idx = tid; idx < BK * BM; idx += kB) {
-        const int kk = idx / BM, mm = idx - kk * BM;
-        const int m = m0 + mm, k = k0 + kk;
-        float v = 0.f;
-        if (m < M && k < k_hi) {
-          v = A[(size_t)k * lda + m];
-          if (rs) v *= rs[(size_t)k * rs_ld];
-        }
-        As[kk][mm] = v;
-      }
-    } else {        // stored (M x K): k contiguous
-#pragma unroll 4
-      for (int idx = tid; idx < BK * BM; idx += kB) {
-        const int mm = idx / BK, kk = idx - mm * BK;
-        const int m = m0 + mm, k = k0 + kk;
-        float v = 0.f;
-        if (m < M && k < k_hi) {
-          v = A[(size_t)m * lda + k];
-          if (rs) v *= rs[(size_t)m * rs_ld];
-        }
-        As[kk][mm] = v;
-      }
+#pragma unroll
+    for (int it = 0; it < kALoads; ++it) {
+      const int idx = tid + it * kB;
+      if (TA) As[idx / BM][idx % BM] = va[it];
+      else As[idx % BK][idx / BK] = va[it];
     }
-    if (transB) {   // stored (N x K): k contiguous
-#pragma unroll 4
-      for (int idx = tid; idx < BK * BN; idx += kB) {
-        const int nn = idx / BK, kk = idx - nn * BK;
-        const int n = n0 + nn, k = k0 + kk;
-        Bs[kk][nn] = (n < N && k < k_hi) ? Bm[(size_t)n * ldb + k] : 0.f;
-      }
-    } else {        // stored (K x N): n contiguous
-#pragma unroll 4
-      for (int idx = tid; idx < BK * BN; idx += kB) {
-        const int kk = idx / BN, nn = idx - kk * BN;
-        const int n = n0 + nn, k = k0 + kk;
-        Bs[kk][nn] = (n < N && k < k_hi) ? Bm[(size_t)k * ldb + n] : 0.f;
-      }
+#pragma unroll
+    for (int it = 0; it < kBLoads; ++it) {
+      const int idx = tid + it * kB;
+      if (TB) Bs[idx % BK][idx / BK] = vb[it];
+      else Bs[idx / BN][idx % BN] = vb[it];
     }
     __syncthreads();
+    if (k0 + BK < k_hi) {   // the next chunk is in flight while the matrix cores run
+      fetch_a<TA>(va, A, rs, lda, rs_ld, M, m0, k0 + BK, k_hi, tid);
+      fetch_b<TB>(vb, Bm, ldb, N, n0, k0 + BK, k_hi, tid);
+    }
     if (want_cs && tid < BM) {
 #pragma unroll
       for (int kk = 0; kk < BK; ++kk) cs += As[kk][tid];
@@ -154,6 +169,24 @@ __global__ __launch_bounds__(kB) void gemm_mfma_kernel(const GemmTable T) {
       *c = v;
     }
   }
+}
+
+// C = beta*C + alpha*op(A)op(B) (+bias)(relu)(mask), or with GN_GEMM_ACCUM: C += alpha*op(A)op(B) by atomics
+// (K split over workgroups).  fp32 matrix cores (v_mfma_f32_32x32x2_f32), operands staged through LDS
+// k-major so that either storage order of A and B loads coalesced.
+__global__ __launch_bounds__(kB) void gemm_mfma_kernel(const GemmTable T) {
+  __shared__ float As[BK][BM + 4];
+  __shared__ float Bs[BK][BN + 4];
+  int g = 0;
+  for (int i = 1; i < T.n; ++i)
+    if ((int)blockIdx.x >= T.d[i].tile0) g = i;
+  g = gn_uniform(g);
+  const GemmDesc& D = T.d[g];
+  const int tt = gn_uniform(D.flags & (GN_GEMM_TRANS_A | GN_GEMM_TRANS_B));
+  if (tt == 0) gemm_body<false, false>(D, As, Bs);
+  else if (tt == GN_GEMM_TRANS_A) gemm_body<true, false>(D, As, Bs);
+  else if (tt == GN_GEMM_TRANS_B) gemm_body<false, true>(D, As, Bs);
+  else gemm_body<true, true>(D, As, Bs);
 }
 
 __global__ __launch_bounds__(kB) void scale_kernel(float* __restrict__ C, long long total, int N, int ldc, float beta) {
@@ -205,28 +238,45 @@ __global__ __launch_bounds__(kB) void rowdot_kernel(const float* __restrict__ a,
 //   dsig = sum_k def_k dist_k;  ddist_k = def_k sig + gdist_k;  df = dsig sig (1 - sig);
 //   dlogits_k = dist_k (ddist_k - sum_j ddist_j dist_j) / tau.
 // lgf (rows, ldl): column K holds the factor pre-activation f.  dlgf (rows, ldl): columns 0..K-1 <- dlogits,
-// column K <- df, the rest 0.
+// column K <- df, the rest 0.  sym_N > 0: rows are the unordered pairs of the pairwise graph — one row of
+// logits fed the two ordered edges (i,j), (j,i) of dist (each with its own noise), def is the gradient of
+// ef_ij + ef_ji, and the row receives the sum over its ordered edges.
 __global__ __launch_bounds__(kB) void gumbel_bwd_kernel(const float* __restrict__ dist, const float* __restrict__ lgf,
                                                         const float* __restrict__ def, const float* __restrict__ gdist,
                                                         float* __restrict__ dlgf, long long rows, int K, int ldl,
-                                                        float tau) {
+                                                        float tau, int sym_N) {
+  const int P = sym_N > 0 ? gn_pair_count(sym_N) : 1;
   for (long long r = (long long)blockIdx.x * kB + threadIdx.x; r < rows; r += (long long)gridDim.x * kB) {
     const float f = lgf[r * ldl + K];
     const float sig = 1.f / (1.f + expf(-f));
-    float dsig = 0.f, dot = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const float d = dist[r * K + k], de = def[r * K + k];
-      dsig += de * d;
-      const float dd = de * sig + (gdist ? gdist[r * K + k] : 0.f);
-      dot += dd * d;
+    // rows of dist / gdist this row of logits fed: itself, or with sym_N the ordered edges (i,j) and (j,i)
+    long long e[2] = {r, -1};
+    if (sym_N > 0) {
+      const long long b = r / P;
+      int i, j;
+      gn_pair_decode((int)(r - b * P), sym_N, i, j);
+      e[0] = (b * sym_N + i) * sym_N + j;
+      e[1] = i == j ? -1 : (b * sym_N + j) * sym_N + i;
     }
-    for (int k = 0; k < K; ++k) {
-      const float d = dist[r * K + k];
-      const float dd = def[r * K + k] * sig + (gdist ? gdist[r * K + k] : 0.f);
-      dlgf[r * ldl + k] = d * (dd - dot) / tau;
+    float df = 0.f;
+    for (int k = 0; k < ldl; ++k) dlgf[r * ldl + k] = 0.f;
+    for (int s = 0; s < 2; ++s) {
+      if (e[s] < 0) continue;
+      const float* d_ = dist + e[s] * K;
+      const float* gd = gdist ? gdist + e[s] * K : nullptr;
+      float dsig = 0.f, dot = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float d = d_[k], de = def[r * K + k];
+        dsig += de * d;
+        dot += (de * sig + (gd ? gd[k] : 0.f)) * d;
+      }
+      for (int k = 0; k < K; ++k) {
+        const float dd = def[r * K + k] * sig + (gd ? gd[k] : 0.f);
+        dlgf[r * ldl + k] += d_[k] * (dd - dot) / tau;
+      }
+      df += dsig * sig * (1.f - sig);
     }
-    dlgf[r * ldl + K] = dsig * sig * (1.f - sig);
-    for (int k = K + 1; k < ldl; ++k) dlgf[r * ldl + k] = 0.f;
+    dlgf[r * ldl + K] = df;
   }
 }
 
@@ -330,6 +380,141 @@ __global__ __launch_bounds__(kB) void node2edge_bwd_kernel(const float* __restri
   if (live && lane == 0) atomicAdd(db2, db2l);
 }
 
+// The same backward, one WORKGROUP per scene (N small enough for LDS): a scene owns its node rows, so the
+// gradients of x' and pq are accumulated in LDS (ds_add) and written once — no global atomics except the
+// 33 attention-layer-1 sums per scene.  H == nullptr selects the implicit pairwise graph (E = N*N, edge
+// e = i*N + j joins i and j with weight 1, weight 2 on i when i == j; model/MS_HGNN_batch.py:143-160), or
+// with sym its N(N+1)/2 unordered pairs (the two ordered edges of a pair pool the same feature).
+__global__ __launch_bounds__(kB) void node2edge_bwd_scene_kernel(
+    const float* __restrict__ xp, const float* __restrict__ pq, const float* __restrict__ H,
+    const float* __restrict__ w2, float b2, const float* __restrict__ dedges, float* __restrict__ dxp,
+    float* __restrict__ dpq, float* __restrict__ dw2, float* __restrict__ db2, int N, int E, int sym) {
+  extern __shared__ __align__(16) float lds[];
+  const int NF = N * GN_FEAT;
+  float* s_xp = lds;
+  float* s_pq = s_xp + NF;
+  float* s_dxp = s_pq + NF;
+  float* s_dpq = s_dxp + NF;
+  float* s_red = s_dpq + NF;               // 64: dw2 (32) and db2 of the workgroup
+  const int wave = gn_uniform((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63, c = lane & 31;
+  float* base = s_red + 64 + (size_t)wave * 4 * N;
+  int* s_idx = reinterpret_cast<int*>(base);
+  float* s_h = base + N;
+  float* s_att = base + 2 * N;
+  float* s_dw = base + 3 * N;
+  const int b = blockIdx.x;
+  const float* xpb = xp + (size_t)b * NF;
+  const float* pqb = pq + (size_t)b * NF;
+  for (int i = threadIdx.x; i < NF; i += kB) {
+    s_xp[i] = xpb[i];
+    s_pq[i] = pqb[i];
+    s_dxp[i] = 0.f;
+    s_dpq[i] = 0.f;
+  }
+  if (threadIdx.x < 64) s_red[threadIdx.x] = 0.f;
+  __syncthreads();
+  const float w2c = w2[c];
+  float dw2c = 0.f, db2l = 0.f;
+  for (int e = wave; e < E; e += kB / 64) {
+    int cnt = 0;
+    if (H == nullptr) {
+      int i, j;
+      if (sym) {       // E = N(N+1)/2 unordered pairs, dedges already summed over (i,j) and (j,i)
+        gn_pair_decode(e, N, i, j);
+      } else {
+        i = e / N;
+        j = e - i * N;
+      }
+      if (lane == 0) {
+        if (i == j) {
+          s_idx[0] = i;
+          s_h[0] = 2.f;
+        } else {
+          s_idx[0] = min(i, j);
+          s_h[0] = 1.f;
+          s_idx[1] = max(i, j);
+          s_h[1] = 1.f;
+        }
+      }
+      cnt = i == j ? 1 : 2;
+    } else {
+      const float* Hrow = H + ((size_t)b * E + e) * N;
+      for (int n0 = 0; n0 < N; n0 += 64) {
+        const int n = n0 + lane;
+        const float hv = n < N ? Hrow[n] : 0.f;
+        const unsigned long long mask = __ballot(hv != 0.f);
+        if (hv != 0.f) {
+          const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+          s_idx[pos] = n;
+          s_h[pos] = hv;
+        }
+        cnt += __popcll(mask);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float qe = 0.f;
+    for (int m = 0; m < cnt; ++m) qe = fmaf(s_h[m], s_pq[s_idx[m] * GN_FEAT + lane], qe);
+    const float qlo = __shfl(qe, 32 + c, GN_WAVE);
+    const float de = dedges[((size_t)b * E + e) * GN_FEAT + lane];
+    for (int m = 0; m < cnt; ++m) {
+      const int n = s_idx[m];
+      float t = lane < 32 ? w2c * fmaxf(s_pq[n * GN_FEAT + c] + qlo, 0.f) : 0.f;
+      t = gn_wave_sum(t);
+      float d = de * s_xp[n * GN_FEAT + lane];
+      d = gn_wave_sum(d);
+      if (lane == 0) {
+        s_att[m] = t + b2;
+        s_dw[m] = d;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float mx = cnt < N ? 0.f : -INFINITY;
+    for (int m = lane; m < cnt; m += 64) mx = fmaxf(mx, s_att[m] * s_h[m]);
+    mx = gn_wave_max(mx);
+    float sum = 0.f;
+    for (int m = lane; m < cnt; m += 64) sum += expf(s_att[m] * s_h[m] - mx);
+    sum = gn_wave_sum(sum);
+    sum += (float)(N - cnt) * expf(0.f - mx);
+    float pd = 0.f;
+    for (int m = lane; m < cnt; m += 64) pd += expf(s_att[m] * s_h[m] - mx) / sum * s_dw[m] * s_h[m];
+    pd = gn_wave_sum(pd);
+    float dq = 0.f;
+    for (int m = 0; m < cnt; ++m) {
+      const int n = s_idx[m];
+      const float hv = s_h[m];
+      const float p = expf(s_att[m] * hv - mx) / sum;
+      atomicAdd(s_dxp + n * GN_FEAT + lane, p * hv * de);
+      const float datt = p * (s_dw[m] * hv - pd) * hv;
+      if (lane < 32) {
+        const float pre = s_pq[n * GN_FEAT + c] + qlo;
+        dw2c = fmaf(datt, fmaxf(pre, 0.f), dw2c);
+        const float dpre = pre > 0.f ? datt * w2c : 0.f;
+        atomicAdd(s_dpq + n * GN_FEAT + c, dpre);
+        dq += dpre;
+      }
+      db2l += datt;
+    }
+    const float dq_hi = __shfl(dq, c, GN_WAVE);
+    if (lane >= 32)
+      for (int m = 0; m < cnt; ++m) atomicAdd(s_dpq + s_idx[m] * GN_FEAT + lane, s_h[m] * dq_hi);
+    __builtin_amdgcn_wave_barrier();   // the lists are rewritten by the next edge of this wave
+  }
+  if (lane < 32) atomicAdd(s_red + c, dw2c);
+  if (lane == 0) atomicAdd(s_red + 32, db2l);
+  __syncthreads();
+  float* dxpb = dxp + (size_t)b * NF;
+  float* dpqb = dpq + (size_t)b * NF;
+  for (int i = threadIdx.x; i < NF; i += kB) {
+    dxpb[i] += s_dxp[i];
+    dpqb[i] += s_dpq[i];
+  }
+  if (threadIdx.x < 32) atomicAdd(dw2 + threadIdx.x, s_red[threadIdx.x]);
+  if (threadIdx.x == 32) atomicAdd(db2, s_red[32]);
+}
+
 // out[r][c] = alpha * a[r][c] + beta * out[r][c] on (rows x cols) blocks with leading dimensions
 __global__ __launch_bounds__(kB) void axpby2d_kernel(float* __restrict__ out, int ldo, const float* __restrict__ a,
                                                      int lda, long long rows, int cols, float alpha, float beta) {
@@ -345,12 +530,26 @@ __global__ __launch_bounds__(kB) void axpby2d_kernel(float* __restrict__ out, in
 
 // ef[r][k] = sigmoid(lgf[r][K]) * dist[r][k]   (edge_feat of MLP_dict_softmax from its saved pieces)
 __global__ __launch_bounds__(kB) void gumbel_ef_kernel(const float* __restrict__ dist, const float* __restrict__ lgf,
-                                                       float* __restrict__ ef, long long rows, int K, int ldl) {
+                                                       float* __restrict__ ef, long long rows, int K, int ldl,
+                                                       int sym_N, float diag_w) {
   const long long total = rows * K;
+  const int P = sym_N > 0 ? gn_pair_count(sym_N) : 1;
   for (long long idx = (long long)blockIdx.x * kB + threadIdx.x; idx < total; idx += (long long)gridDim.x * kB) {
     const long long r = idx / K;
+    const int k = (int)(idx - r * K);
     const float sig = 1.f / (1.f + expf(-lgf[r * ldl + K]));
-    ef[idx] = sig * dist[idx];
+    float d;
+    if (sym_N > 0) {   // pair row: ef_ij + ef_ji (the diagonal has one ordered edge)
+      const long long b = r / P;
+      int i, j;
+      gn_pair_decode((int)(r - b * P), sym_N, i, j);
+      d = dist[((b * sym_N + i) * sym_N + j) * K + k];
+      if (i != j) d += dist[((b * sym_N + j) * sym_N + i) * K + k];
+      else d *= diag_w;
+    } else {
+      d = dist[idx];
+    }
+    ef[idx] = sig * d;
   }
 }
 
@@ -489,24 +688,36 @@ extern "C" int gn_rowdot_f32(const float* a, const float* b, float* out, long lo
 }
 
 extern "C" int gn_gumbel_bwd_f32(const float* dist, const float* lgf, const float* def, const float* gdist, float* dlgf,
-                                 long long rows, int K, int ldl, float tau, gn_stream_t stream) {
+                                 long long rows, int K, int ldl, float tau, int sym_N, gn_stream_t stream) {
   GN_REQUIRE_PTR(dist);
   GN_REQUIRE_PTR(lgf);
   GN_REQUIRE_PTR(def);
   GN_REQUIRE_PTR(dlgf);
-  if (rows <= 0 || K < 1 || ldl <= K || !(tau > 0.f)) return GN_ERR_SHAPE;
+  if (rows <= 0 || K < 1 || ldl <= K || !(tau > 0.f) || sym_N < 0) return GN_ERR_SHAPE;
+  if (sym_N > 0 && rows % gn_pair_count(sym_N) != 0) return GN_ERR_SHAPE;
   hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(cap_grid(rows, kB)), dim3(kB), 0, (hipStream_t)stream, dist, lgf, def,
-                     gdist, dlgf, rows, K, ldl, tau);
+                     gdist, dlgf, rows, K, ldl, tau, sym_N);
   return gn_check_launch();
 }
 
 extern "C" int gn_node2edge_bwd_f32(const float* xp, const float* pq, const float* H, const float* w2, float b2,
                                     const float* dedges, float* dxp, float* dpq, float* dw2, float* db2, int B, int N,
-                                    int E, gn_stream_t stream) {
-  const void* ptrs[] = {xp, pq, H, w2, dedges, dxp, dpq, dw2, db2};
+                                    int E, int sym, gn_stream_t stream) {
+  const void* ptrs[] = {xp, pq, w2, dedges, dxp, dpq, dw2, db2};
   for (const void* p : ptrs)
     if (p == nullptr) return GN_ERR_NULL;
   if (B <= 0 || N <= 0 || E <= 0) return GN_ERR_SHAPE;
+  if (sym && H != nullptr) return GN_ERR_SHAPE;
+  if (H == nullptr && E != (sym ? gn_pair_count(N) : N * N)) return GN_ERR_SHAPE;
+  // one workgroup per scene while the scene's node rows (x', pq and their gradients) fit in LDS
+  const size_t scene_lds = ((size_t)4 * N * GN_FEAT + 64 + (size_t)(kB / 64) * 4 * N) * sizeof(float);
+  if (scene_lds <= 150 * 1024) {
+    if (scene_lds > 64 * 1024) gn_allow_big_lds(node2edge_bwd_scene_kernel);
+    hipLaunchKernelGGL(node2edge_bwd_scene_kernel, dim3((unsigned)B), dim3(kB), scene_lds, (hipStream_t)stream, xp, pq,
+                       H, w2, b2, dedges, dxp, dpq, dw2, db2, N, E, sym);
+    return gn_check_launch();
+  }
+  if (H == nullptr) return GN_ERR_LDS;     // large-N pairwise: hand in the explicit incidence
   const size_t lds = (size_t)(kB / 64) * 4 * N * sizeof(float);
   if (lds > 64 * 1024) return GN_ERR_LDS;
   const long long total = (long long)B * E;
@@ -528,13 +739,14 @@ extern "C" int gn_axpby2d_f32(float* out, int ldo, const float* a, int lda, long
 }
 
 extern "C" int gn_gumbel_ef_f32(const float* dist, const float* lgf, float* ef, long long rows, int K, int ldl,
-                                gn_stream_t stream) {
+                                int sym_N, float diag_w, gn_stream_t stream) {
   GN_REQUIRE_PTR(dist);
   GN_REQUIRE_PTR(lgf);
   GN_REQUIRE_PTR(ef);
-  if (rows <= 0 || K < 1 || ldl <= K) return GN_ERR_SHAPE;
+  if (rows <= 0 || K < 1 || ldl <= K || sym_N < 0) return GN_ERR_SHAPE;
+  if (sym_N > 0 && rows % gn_pair_count(sym_N) != 0) return GN_ERR_SHAPE;
   hipLaunchKernelGGL(gumbel_ef_kernel, dim3(cap_grid(rows * K, kB)), dim3(kB), 0, (hipStream_t)stream, dist, lgf, ef,
-                     rows, K, ldl);
+                     rows, K, ldl, sym_N, diag_w);
   return gn_check_launch();
 }
 

@@ -292,8 +292,16 @@ int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, 
  * gn_gumbel_bwd_f32: back through edge_feat = sigmoid(f) * dist, dist = softmax((logits + g)/tau)
  *   (model/MS_HGNN_batch.py:45-50): dist (rows,K), lgf (rows,ldl) whose column K is f, def = d edge_feat,
  *   gdist = d dist or NULL -> dlgf (rows,ldl): columns 0..K-1 = d logits, column K = d f, rest 0.
- * gn_node2edge_bwd_f32: back through gn_node2edge_f32 for an explicit H (B,E,N): given dedges (B,E,64)
- *   ADDS into dxp (B,N,64), dpq (B,N,64), dw2 (32), db2 (1) (atomics; zero them first). */
+ *   sym_N > 0 (here and in gn_gumbel_ef_f32): the rows of lgf / def / dlgf / ef are the N(N+1)/2 unordered
+ *   pairs of the pairwise graph per scene, dist / gdist stay per ordered edge (B, N*N, K): a pair row
+ *   stands for the ordered edges (i,j) and (j,i) — ef is their sum (self-loop rows times diag_w: 2 gives the
+ *   rows the forward's pair-form aggregation consumes, which fold H = 2 into ef), dlgf the sum of their
+ *   gradients.
+ * gn_node2edge_bwd_f32: back through gn_node2edge_f32 for an explicit H (B,E,N), or H == NULL for the
+ *   implicit pairwise graph (E == N*N ordered edges, or with sym its N(N+1)/2 unordered pairs whose dedges
+ *   are already summed over the two directions): given dedges (B,E,64) ADDS into dxp (B,N,64),
+ *   dpq (B,N,64), dw2 (32), db2 (1) (zero them first).  One workgroup per scene with the scene's rows in
+ *   LDS while they fit (N <= ~140); beyond that one wave per hyperedge with global atomics (explicit H only). */
 /* Grouped form: n independent problems in one launch (all types of the typed aggregation MLP, all modules
  * of a multiscale block).  rs (optional) scales A's STORED rows: A_eff[r][:] = rs[r*rs_ld] * A[r][:];
  * colsum (optional, GN_GEMM_TRANS_A only) receives colsum[m] += sum_k A_eff[k][m] — the bias gradient next
@@ -325,8 +333,8 @@ int gn_axpby2d_f32(float* out, int ldo, const float* a, int lda, long long rows,
                    float beta, gn_stream_t stream);
 /* ef[r][k] = sigmoid(lgf[r][K]) * dist[r][k]: edge_feat of MLP_dict_softmax from dist and the factor
  * pre-activation (column K of lgf (rows, ldl)). */
-int gn_gumbel_ef_f32(const float* dist, const float* lgf, float* ef, long long rows, int K, int ldl,
-                     gn_stream_t stream);
+int gn_gumbel_ef_f32(const float* dist, const float* lgf, float* ef, long long rows, int K, int ldl, int sym_N,
+                     float diag_w, gn_stream_t stream);
 /* Middle of the typed aggregation MLP's backward (model/MS_HGNN_batch.py:264-265), all K types of a row at
  * once: T (rows, K*hid) holds dfeat W2cat, Hc (rows, K*hid) the hidden activations; writes
  * def[r][k] = <T[r,k,:], Hc[r,k,:]> + <dfeat[r], b2[k]> and T[r,k,:] <- ef[r][k] * T[r,k,:] * (Hc > 0). */
@@ -338,10 +346,10 @@ int gn_rowscale_f32(float* dst, const float* src, const float* s, long long rows
 int gn_rowdot_f32(const float* a, const float* b, float* out, long long rows, int cols, int ldo, int off,
                   gn_stream_t stream);
 int gn_gumbel_bwd_f32(const float* dist, const float* lgf, const float* def, const float* gdist, float* dlgf,
-                      long long rows, int K, int ldl, float tau, gn_stream_t stream);
+                      long long rows, int K, int ldl, float tau, int sym_N, gn_stream_t stream);
 int gn_node2edge_bwd_f32(const float* xp, const float* pq, const float* H, const float* w2, float b2,
                          const float* dedges, float* dxp, float* dpq, float* dw2, float* db2, int B, int N,
-                         int E, gn_stream_t stream);
+                         int E, int sym, gn_stream_t stream);
 
 /* ---- device noise (build's own; the reference draws torch.rand on the host) --------------------
  * U[i] = Philox4x32-10(counter = (i + offset) / 4, key = seed)[(i + offset) % 4] >> 8, scaled to
