@@ -242,6 +242,22 @@ def _param_key(params: Iterable[nn.Parameter]):
     return tuple((p.data_ptr(), p._version) for p in params)
 
 
+def invalidate_weight_caches(module: nn.Module) -> None:
+    """Drop every packed / concatenated weight image below `module`.  They are keyed on the parameters'
+    (address, in-place version); anything that rewrites parameters behind autograd's back — a replayed
+    hipGraph containing the optimizer step — must call this before the next eager use."""
+    for m in module.modules():
+        d = m.__dict__
+        if "_pk" in d:
+            m._pk, m._pk_key = None, None
+        for name in ("_pk_n2e", "_pk_mlp"):
+            if name in d:
+                d[name].clear()
+        d.pop("_bwd_cat", None)
+        if "_affine" in d:
+            m._affine = None
+
+
 class _MessagePassing(nn.Module):
     """What both reference modules share: one or more node->edge->node rounds
     (model/MS_HGNN_batch.py:174-195, 425-441)."""
@@ -290,7 +306,7 @@ class _MessagePassing(nn.Module):
                 bpq = torch.cat((a0.bias, torch.zeros_like(a0.bias)), 0).contiguous()
                 pk = dict(W=ops.pack_stream([s0.weight, s1.weight, Wpq]),
                           bias=ops.bias_stream([s0.bias, s1.bias, bpq]),
-                          w2=a1.weight.detach()[0].contiguous().clone(), b2=float(a1.bias.detach()[0].item()))
+                          w2=a1.weight.detach()[0], b2=a1.bias.detach())    # views of the parameters: no host sync
             self._pk_n2e[idx] = (key, pk)
             hit = self._pk_n2e[idx]
         return hit[1]

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -30,7 +30,7 @@ class NodeGroup(ctypes.Structure):      # gn_node_group_t
 
 
 class N2EGroup(ctypes.Structure):       # gn_n2e_group_t
-    _fields_ = [("xp", _P), ("pq", _P), ("H", _P), ("w2", _P), ("edges", _P), ("b2", _F), ("E", _I), ("sym", _I)]
+    _fields_ = [("xp", _P), ("pq", _P), ("H", _P), ("w2", _P), ("edges", _P), ("b2", _P), ("E", _I), ("sym", _I)]
 
 
 class EdgeGroup(ctypes.Structure):      # gn_edge_group_t
@@ -97,7 +97,7 @@ SIGNATURES = {
     "gn_rowscale_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _I, _I, _I, _P]),
     "gn_rowdot_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _I, _I, _I, _P]),
     "gn_gumbel_bwd_f32": (_I, [_P, _P, _P, _P, _P, ctypes.c_longlong, _I, _I, _F, _I, _P]),
-    "gn_node2edge_bwd_f32": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "gn_node2edge_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "gn_philox_uniform_f32": (_I, [_P, _SZ, _U64, _U64, _P, _P]),
     "gn_counter_add_u64": (_I, [_P, _U64, _P]),
 }

@@ -361,7 +361,7 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
             c["dxp"], c["dpq"] = pool.take(BN, D), pool.take(BN, D)
             grads[c["a1"].weight], grads[c["a1"].bias] = pool.take(1, 32), pool.take(1)
             with torch.cuda.device(dev):
-                check(load().gn_node2edge_bwd_f32(_p(c["xp"]), _p(c["pq"]), _p(c["H"]), _p(c["w2"]), c["b2"],
+                check(load().gn_node2edge_bwd_f32(_p(c["xp"]), _p(c["pq"]), _p(c["H"]), _p(c["w2"]), _p(c["b2"]),
                                                   _p(c["dedges"]), _p(c["dxp"]), _p(c["dpq"]), _p(grads[c["a1"].weight]),
                                                   _p(grads[c["a1"].bias]), c["B"], c["N"], c["E"], int(c["sym"]),
                                                   stream_handle()),

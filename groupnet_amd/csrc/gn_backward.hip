@@ -284,11 +284,13 @@ __global__ __launch_bounds__(kB) void gumbel_bwd_kernel(const float* __restrict_
 // kernel does).  Accumulates (atomics) into dxp (B,N,64), dpq (B,N,64) = [dP | dQn], dw2 (32), db2 (1).
 __global__ __launch_bounds__(kB) void node2edge_bwd_kernel(const float* __restrict__ xp, const float* __restrict__ pq,
                                                            const float* __restrict__ H, const float* __restrict__ w2,
-                                                           float b2, const float* __restrict__ dedges,
+                                                           const float* __restrict__ b2p,
+                                                           const float* __restrict__ dedges,
                                                            float* __restrict__ dxp, float* __restrict__ dpq,
                                                            float* __restrict__ dw2, float* __restrict__ db2, int N,
                                                            int E, long long total_edges) {
   extern __shared__ __align__(16) float lds[];
+  const float b2 = *b2p;
   const int wave = gn_uniform((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, c = lane & 31;
   const long long eg_raw = (long long)blockIdx.x * (kB / 64) + wave;
@@ -387,9 +389,11 @@ __global__ __launch_bounds__(kB) void node2edge_bwd_kernel(const float* __restri
 // with sym its N(N+1)/2 unordered pairs (the two ordered edges of a pair pool the same feature).
 __global__ __launch_bounds__(kB) void node2edge_bwd_scene_kernel(
     const float* __restrict__ xp, const float* __restrict__ pq, const float* __restrict__ H,
-    const float* __restrict__ w2, float b2, const float* __restrict__ dedges, float* __restrict__ dxp,
+    const float* __restrict__ w2, const float* __restrict__ b2p, const float* __restrict__ dedges,
+    float* __restrict__ dxp,
     float* __restrict__ dpq, float* __restrict__ dw2, float* __restrict__ db2, int N, int E, int sym) {
   extern __shared__ __align__(16) float lds[];
+  const float b2 = *b2p;
   const int NF = N * GN_FEAT;
   float* s_xp = lds;
   float* s_pq = s_xp + NF;
@@ -700,10 +704,10 @@ extern "C" int gn_gumbel_bwd_f32(const float* dist, const float* lgf, const floa
   return gn_check_launch();
 }
 
-extern "C" int gn_node2edge_bwd_f32(const float* xp, const float* pq, const float* H, const float* w2, float b2,
+extern "C" int gn_node2edge_bwd_f32(const float* xp, const float* pq, const float* H, const float* w2, const float* b2,
                                     const float* dedges, float* dxp, float* dpq, float* dw2, float* db2, int B, int N,
                                     int E, int sym, gn_stream_t stream) {
-  const void* ptrs[] = {xp, pq, w2, dedges, dxp, dpq, dw2, db2};
+  const void* ptrs[] = {xp, pq, w2, b2, dedges, dxp, dpq, dw2, db2};
   for (const void* p : ptrs)
     if (p == nullptr) return GN_ERR_NULL;
   if (B <= 0 || N <= 0 || E <= 0) return GN_ERR_SHAPE;

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_kernel(GroupTable<gn_n2e_gro
     const float p = pqb[(size_t)n * GN_FEAT + c];
     float t = valid ? w2c * fmaxf(p + qlo, 0.f) : 0.f;
     t = gn_half_sum(t);
-    if (valid && c == 0) s_att[m] = t + G.b2;
+    if (valid && c == 0) s_att[m] = t + *G.b2;
   }
   __syncthreads();
   // softmax over all N nodes of v_n = att_n * H[e,n]  (0 for non-members)
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
   extern __shared__ __align__(16) float lds[];
   constexpr int LDP = GN_FEAT + 1;
   const bool sym = G.sym != 0;
+  const float b2v = *G.b2;
   const int E = sym ? gn_pair_count(N) : N * N;   // edge rows per scene
   const int b0 = (blockIdx.x / bands) * SG;
   const int band = blockIdx.x % bands;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
       if (i == j) {
 #pragma unroll 8
         for (int cch = 0; cch < 32; ++cch) ai = fmaf(s_w2[cch], fmaxf(pi[cch] + 2.f * pi[32 + cch], 0.f), ai);
-        ai += G.b2;
+        ai += b2v;
         // H = 2 on the self-loop: v = 2*att, the other N-1 nodes contribute exp(0)
         const float v = 2.f * ai;
         const float mx = N > 1 ? fmaxf(v, 0.f) : v;
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
           ai = fmaf(s_w2[cch], fmaxf(pi[cch] + q, 0.f), ai);
           aj = fmaf(s_w2[cch], fmaxf(pj[cch] + q, 0.f), aj);
         }
-        ai += G.b2;
-        aj += G.b2;
+        ai += b2v;
+        aj += b2v;
         const float mx = N > 2 ? fmaxf(fmaxf(ai, aj), 0.f) : fmaxf(ai, aj);
         const float ei = expf(ai - mx), ej = expf(aj - mx);
         const float sum = (ei + ej) + (float)(N - 2) * expf(0.f - mx);
@@ -599,7 +600,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) 
 
 }  // namespace
 
-extern "C" int gn_abi_version(void) { return 14; }
+extern "C" int gn_abi_version(void) { return 15; }
 
 extern "C" const char* gn_strerror(int code) {
   switch (code) {
@@ -696,7 +697,7 @@ extern "C" int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int 
   long long waves = 0;
   for (int g = 0; g < n_groups; ++g) {
     const gn_n2e_group_t& G = groups[g];
-    if (!G.xp || !G.pq || !G.w2 || !G.edges) return GN_ERR_NULL;
+    if (!G.xp || !G.pq || !G.w2 || !G.b2 || !G.edges) return GN_ERR_NULL;
     if (G.E <= 0) return GN_ERR_SHAPE;
     if (!gn_aligned16(G.xp) || !gn_aligned16(G.edges)) return GN_ERR_ALIGN;
     if (G.H == nullptr) {

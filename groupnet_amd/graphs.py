@@ -11,7 +11,7 @@ graph itself advances at the end of every replay — each replay draws fresh, re
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Callable, Optional, Sequence, Tuple
 
 import torch
 
@@ -70,3 +70,70 @@ class GraphedMultiScale:
             self.f_in.copy_(f, non_blocking=True)
         self.graph.replay()
         return self.out, self.H
+
+
+class GraphedTrainStep:
+    """One training step of a ``MultiScaleHGNN`` block — forward, loss, backward and the optimizer update —
+    captured in ONE hipGraph (`train_hyper_nba.py:107-118` is this loop).
+
+    Eagerly a step is ~150 launches whose host side (autograd bookkeeping, descriptor tables, allocations)
+    takes several times longer than the GPU work; replayed from a graph the step runs at GPU speed.
+
+        step = GraphedTrainStep(block, opt, loss_fn, B, N, target_shapes=[(B, N, 2)], seed=7)
+        loss = step(f, target)        # copies into the graph's static inputs, replays, returns the loss tensor
+
+    ``loss_fn(final_feature, new_H, *targets) -> scalar``.  Noise is the device Philox stream, advanced inside
+    the graph so every replay draws fresh Gumbel noise.  Everything that depends on parameter values (packed
+    weight images) is rebuilt inside the graph; after a replay the eager caches are dropped, so eager calls
+    between replays see the updated parameters.  Optimizers must be capturable (SGD is; Adam with
+    ``capturable=True``)."""
+
+    def __init__(self, block: MultiScaleHGNN, optimizer: torch.optim.Optimizer, loss_fn: Callable, B: int, N: int,
+                 target_shapes: Sequence[Tuple[int, ...]] = (), seed: int = 0, warmup: int = 3):
+        p = next(block.parameters())
+        self.device = p.device
+        if self.device.type != "cuda":
+            raise ValueError("GraphedTrainStep needs the block on a GPU")
+        self.block, self.optimizer, self.loss_fn = block, optimizer, loss_fn
+        self.seed = int(seed)
+        self.f_in = torch.zeros((B, N, block.h_dim), dtype=torch.float32, device=self.device)
+        self.targets = [torch.zeros(tuple(s), dtype=torch.float32, device=self.device) for s in target_shapes]
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.draws_per_step = sum(b * e * k for (b, e, k) in block.noise_shapes(B, N)) * block.interaction.nmp_layers
+        self.graph = torch.cuda.CUDAGraph()
+        prev = (_mods._NoiseState.mode, _mods._NoiseState.seed, _mods._NoiseState.offset, _mods._NoiseState.counter)
+        try:
+            with torch.cuda.device(self.device):
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    for _ in range(max(1, warmup)):
+                        self._step()
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                torch.cuda.synchronize(self.device)
+                self.counter.fill_(-self.draws_per_step)
+                _mods.invalidate_weight_caches(block)       # every packing kernel must be part of the graph
+                optimizer.zero_grad(set_to_none=True)       # gradients are allocated from the graph's pool
+                with torch.cuda.graph(self.graph):
+                    self.loss = self._step()
+                _mods.invalidate_weight_caches(block)
+        finally:
+            _mods.set_noise_mode(prev[0], prev[1], prev[2], prev[3])
+
+    def _step(self) -> Tensor:
+        _mods.set_noise_mode("device", seed=self.seed, offset=0, counter=self.counter)
+        self.optimizer.zero_grad(set_to_none=True)
+        out, H = self.block(self.f_in, advance=(self.counter, self.draws_per_step))
+        loss = self.loss_fn(out, H, *self.targets)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, f: Optional[Tensor] = None, *targets: Tensor) -> Tensor:
+        if f is not None:
+            self.f_in.copy_(f, non_blocking=True)
+        for dst, src in zip(self.targets, targets):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        _mods.invalidate_weight_caches(self.block)
+        return self.loss

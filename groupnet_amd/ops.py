@@ -257,7 +257,8 @@ def pair_count(N: int) -> int:
 
 
 def node2edge_grouped(items: Sequence[tuple]) -> List[Tensor]:
-    """items = [(xp, pq, H or None, w2, b2[, sym])] over the same (B, N); returns [edges (B,E,64)].
+    """items = [(xp, pq, H or None, w2 (32,), b2 (1,)[, sym])] over the same (B, N); returns [edges (B,E,64)].
+    w2 / b2 = weight row and bias of attention layer 1, device tensors (the parameters themselves).
     H=None selects the implicit pairwise graph: E = N*N ordered edges, or with sym=True the
     N(N+1)/2 unordered pairs (edges (i,j) and (j,i) carry the same feature)."""
     _groups(len(items))
@@ -278,17 +279,18 @@ def node2edge_grouped(items: Sequence[tuple]) -> List[Tensor]:
             _req(H, "H", (B, None, N))
             E = H.shape[1]
         _req(w2, "w2", (32,))
-        _same_device(xp0, xp, pq, H, w2)
+        _req(b2, "b2", (1,))
+        _same_device(xp0, xp, pq, H, w2, b2)
         edges = torch.empty((B, E, FEAT), dtype=xp.dtype, device=xp.device)
         arr[g] = _lib.N2EGroup(xp.data_ptr(), pq.data_ptr(), 0 if H is None else H.data_ptr(), w2.data_ptr(),
-                               edges.data_ptr(), float(b2), E, int(sym))
+                               edges.data_ptr(), b2.data_ptr(), E, int(sym))
         outs.append(edges)
     with torch.cuda.device(xp0.device):
         check(load().gn_node2edge_f32(arr, len(items), B, N, stream_handle()), "gn_node2edge_f32")
     return outs
 
 
-def node2edge(xp: Tensor, pq: Tensor, H: Optional[Tensor], w2: Tensor, b2: float, sym: bool = False) -> Tensor:
+def node2edge(xp: Tensor, pq: Tensor, H: Optional[Tensor], w2: Tensor, b2: Tensor, sym: bool = False) -> Tensor:
     return node2edge_grouped([(xp, pq, H, w2, b2, sym)])[0]
 
 

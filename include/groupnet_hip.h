@@ -144,7 +144,8 @@ typedef struct {
   const float* H;
   const float* w2;
   float* edges;
-  float b2;
+  const float* b2;   /* device pointer to the scalar bias of attention layer 1 (the parameter itself: no
+                        host read-back, so a training step stays capturable in a hipGraph) */
   int E;
   int sym;
 } gn_n2e_group_t;
@@ -347,7 +348,7 @@ int gn_rowdot_f32(const float* a, const float* b, float* out, long long rows, in
                   gn_stream_t stream);
 int gn_gumbel_bwd_f32(const float* dist, const float* lgf, const float* def, const float* gdist, float* dlgf,
                       long long rows, int K, int ldl, float tau, int sym_N, gn_stream_t stream);
-int gn_node2edge_bwd_f32(const float* xp, const float* pq, const float* H, const float* w2, float b2,
+int gn_node2edge_bwd_f32(const float* xp, const float* pq, const float* H, const float* w2, const float* b2,
                          const float* dedges, float* dxp, float* dpq, float* dw2, float* db2, int B, int N,
                          int E, int sym, gn_stream_t stream);
 

@@ -155,3 +155,51 @@ def test_multiscale_block_trains_one_sgd_step():
     with torch.no_grad():
         out2, H = blk.eval()(f, noise_u=noise)
     assert out2.shape == (6, 11, 256) and bool(torch.isfinite(out2).all())
+
+
+def test_graphed_train_step_matches_eager_and_learns():
+    """fwd + loss + bwd + SGD in one hipGraph: the first replay reproduces an eager step with the same
+    Philox noise bit for bit in the loss and to fp32 rounding (split-K atomics) in the updated weights;
+    further replays keep reducing the loss; eager inference afterwards sees the updated weights."""
+    import copy
+    import groupnet_amd as G
+    from groupnet_amd.graphs import GraphedTrainStep
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    from groupnet_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    B, N = 16, 11
+    blk = MultiScaleHGNN([2, 5, 11]).to(dev).train()
+    ref = copy.deepcopy(blk)
+    f = torch.randn(B, N, 64, device=dev)
+    tgt = torch.randn(B, N, blk.out_features, device=dev)
+    loss_fn = lambda out, H, t: ((out - t) ** 2).mean()
+    step = GraphedTrainStep(blk, torch.optim.SGD(blk.parameters(), lr=0.05), loss_fn, B, N,
+                            target_shapes=[tuple(tgt.shape)], seed=11, warmup=2)
+    # the warm-up steps trained `blk`; restart both from the same weights
+    blk.load_state_dict(ref.state_dict())
+    G.MS_HGNN_batch.invalidate_weight_caches(blk)
+    l0 = float(step(f, tgt))
+    # the same step eagerly on the copy: replay k draws from Philox position k * draws_per_step
+    opt = torch.optim.SGD(ref.parameters(), lr=0.05)
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    G.set_noise_mode("device", seed=11, offset=0, counter=counter)
+    try:
+        out, _ = ref(f)
+        loss = loss_fn(out, None, tgt)
+        loss.backward()
+        opt.step()
+    finally:
+        G.set_noise_mode("host")
+    assert abs(float(loss) - l0) <= 1e-6 * max(1.0, abs(l0))
+    for (n1, p1), (_, p2) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert float((p1 - p2).abs().max()) <= 1e-5 * (1.0 + float(p2.abs().max())), n1
+    losses = [l0] + [float(step()) for _ in range(4)]
+    assert losses[-1] < losses[0]
+    with torch.no_grad():       # eager call between replays sees the trained weights (caches were dropped)
+        G.set_noise_mode("device", seed=11, offset=0, counter=counter)
+        try:
+            out_now, _ = blk.eval()(f)
+        finally:
+            G.set_noise_mode("host")
+    assert float(((out_now - tgt) ** 2).mean()) < l0

@@ -57,8 +57,19 @@ def test_null_and_shape_errors_do_not_launch():
     assert lib.gn_agg_mlp_f32(a, 1, P(0)) == -2                             # K > GN_MAX_TYPES
     a[0].K, a[0].W = 6, 8
     assert lib.gn_agg_mlp_f32(a, 1, P(0)) == -4                             # misaligned weight stream
-    n = (_lib.N2EGroup * 1)(_lib.N2EGroup(16, 16, 0, 16, 16, 0.0, 8))
+    n = (_lib.N2EGroup * 1)(_lib.N2EGroup(16, 16, 0, 16, 16, 16, 8))
     assert lib.gn_node2edge_f32(n, 1, 2, 3, P(0)) == -2                     # pairwise needs E == N*N
+    n[0].b2 = 0
+    assert lib.gn_node2edge_f32(n, 1, 2, 3, P(0)) == -1                     # the bias is a device pointer
+    # backward blocks validate on the host as well
+    d = (_lib.GemmDesc * 1)(_lib.GemmDesc(16, 16, 16, 0, 0, 0, 0, 4, 4, 4, 4, 4, 3, 0, 0, 0, 1.0, 0.0))
+    assert lib.gn_gemm_grouped_f32(d, 1, P(0)) == -2                        # ldc < N
+    d[0].ldc, d[0].colsum = 4, 16
+    assert lib.gn_gemm_grouped_f32(d, 1, P(0)) == -2                        # colsum needs GN_GEMM_TRANS_A
+    assert lib.gn_gemm_grouped_f32(None, 1, P(0)) == -1
+    assert lib.gn_node2edge_bwd_f32(P(16), P(16), P(0), P(16), P(16), P(16), P(16), P(16), P(16), P(16), 2, 3, 8, 0,
+                                    P(0)) == -2                             # pairwise: E == N*N
+    assert lib.gn_gumbel_bwd_f32(P(16), P(16), P(16), P(0), P(16), 7, 6, 32, 0.5, 3, P(0)) == -2   # rows % pairs
     e = (_lib.EdgeGroup * 1)(_lib.EdgeGroup(16, 0, 16, 16, 16, 16, 0, 10, 16))
     assert lib.gn_edge_mlp_gumbel_f32(e, 1, 0.5, 0, P(0), P(0)) == -2       # K > 15
     e[0].K = 10
