@@ -127,6 +127,28 @@ def time_kernel_ms(fn, reps=20, warm=3):
     return a.elapsed_time(b) / reps
 
 
+def train_step_leg(N, B, dev, replays=30):
+    """Forward + MSE loss + backward + SGD update of the same block, captured once (groupnet_amd.graphs.
+    GraphedTrainStep) and replayed; a side figure next to the forward metric, not part of `value`."""
+    from groupnet_amd.graphs import GraphedTrainStep
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    torch.manual_seed(1)
+    blk = MultiScaleHGNN(SCALES).to(dev).train()
+    f = torch.randn(B, N, 64, device=dev)
+    tgt = torch.randn(B, N, blk.out_features, device=dev)
+    step = GraphedTrainStep(blk, torch.optim.SGD(blk.parameters(), lr=1e-3), lambda o, H, t: ((o - t) ** 2).mean(),
+                            B, N, [tuple(tgt.shape)], seed=1)
+    step(f, tgt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(replays):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / replays * 1e3
+    return dict(what="forward + MSE loss + backward + SGD step of the same block, one hipGraph replay per step",
+                scenes=B, ms_per_step=round(ms, 3), scenes_per_s=round(B / (ms * 1e-3), 1), replays=replays)
+
+
 def cpu_baseline(block_state, B, N, threads, budget_s=20.0):
     """The oracle on the host cores: same workload (B scenes, pairwise + 3 scales), host noise drawn
     as the reference does.  Bounded sample: as many full forwards as fit in ~budget_s (>= 2)."""
@@ -242,7 +264,7 @@ def main():
             elapsed = float(t.item())
 
         # ---- roofline leg: instrumented eager pass over the same K steps (rank 0) -------------------
-        roof = agg = mfma_kernels = None
+        roof = agg = mfma_kernels = train = None
         if rank == 0:
             G.set_noise_mode("device", seed=99)
             probe = Probe()
@@ -286,6 +308,11 @@ def main():
                        gather_us=round(t_g * 1e3, 2), scatter_us=round(t_s * 1e3, 2),
                        bytes_per_launch_pair=by)
             G.set_noise_mode("host")
+            # ---- one training step (fwd + loss + bwd + SGD) replayed from one hipGraph ------
+            try:
+                train = train_step_leg(N, Bl, dev) if world == 1 else None
+            except Exception as e:      # the headline forward numbers stand on their own
+                train = dict(error=f"{type(e).__name__}: {e}")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -308,7 +335,8 @@ def main():
                                    + (", + all-gather of (B,N,320) embeddings over RCCL" if world > 1 else ""),
                        "global_batch": B_total, "agents": N, "scales": SCALES,
                        "parallelism": f"batch-sharded x{world}"},
-            "roofline": roof, "agg_hbm": agg, "mfma_kernels": mfma_kernels, "cpu_baseline": cpu,
+            "roofline": roof, "agg_hbm": agg, "mfma_kernels": mfma_kernels, "train_step": train,
+            "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -123,8 +123,9 @@ class GraphedTrainStep:
     def _step(self) -> Tensor:
         _mods.set_noise_mode("device", seed=self.seed, offset=0, counter=self.counter)
         self.optimizer.zero_grad(set_to_none=True)
-        out, H = self.block(self.f_in, advance=(self.counter, self.draws_per_step))
-        loss = self.loss_fn(out, H, *self.targets)
+        with torch.enable_grad():
+            out, H = self.block(self.f_in, advance=(self.counter, self.draws_per_step))
+            loss = self.loss_fn(out, H, *self.targets)
         loss.backward()
         self.optimizer.step()
         return loss.detach()
