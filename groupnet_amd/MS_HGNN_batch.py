@@ -515,6 +515,16 @@ class MS_HGNN_hyper(_MessagePassing):
         ops._req(feat_corr, "corr", (feat.shape[0], feat.shape[1], feat.shape[1]))
         return ops.topk_incidence(feat_corr, [int(scale_factor)])[0]
 
+    def init_adj_attention_listall(self, feat, feat_corr, scale_factor=2):
+        """H (B,E,N) by exhaustive search of the best group per agent (model/MS_HGNN_batch.py:390-414);
+        used by forward when ``self.listall`` is set (hard-coded False in the reference, :312)."""
+        ops._req(feat_corr, "corr", (feat.shape[0], feat.shape[1], feat.shape[1]))
+        return ops.listall_incidence(feat_corr, int(scale_factor))
+
+    def _build_H(self, h_states, corr):
+        build = self.init_adj_attention_listall if self.listall else self.init_adj_attention
+        return build(h_states, corr, scale_factor=self.scale)
+
     def node2edge(self, x, H, idx=0):
         return self._node2edge(x, H, idx)
 
@@ -528,7 +538,7 @@ class MS_HGNN_hyper(_MessagePassing):
         if h_states.shape[0] and _needs_grad(self, h_states):
             # H is a constant of the backward (top-k selection has no gradient; corr is only used to build it)
             if H is None:
-                H = self.init_adj_attention(h_states.detach(), corr.detach(), scale_factor=self.scale)
+                H = self._build_H(h_states.detach(), corr.detach())
             node_feat, factor = self._forward_autograd(h_states, H, noise_u, out)
             return node_feat, factor, H
         if h_states.shape[0] == 0:                  # empty batch: nothing to launch
@@ -539,7 +549,7 @@ class MS_HGNN_hyper(_MessagePassing):
             nf = out if out is not None else h_states.new_empty((B, N, self.bottleneck_dim))
             return nf, h_states.new_empty((B, E, self.edge_types)), h_states.new_empty((B, E, N))
         if H is None:
-            H = self.init_adj_attention(h_states, corr, scale_factor=self.scale)
+            H = self._build_H(h_states, corr)
         else:
             ops._req(H, "H", (h_states.shape[0], None, h_states.shape[1]))
         node_feat, factor = self._run(h_states, H, H.shape[1], noise_u, out)

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -76,6 +76,7 @@ SIGNATURES = {
     "gn_strerror": (ctypes.c_char_p, [_I]),
     "gn_affinity_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "gn_topk_incidence_f32": (_I, [_P, ctypes.POINTER(_P), ctypes.POINTER(_I), _I, _I, _I, _P]),
+    "gn_listall_incidence_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "gn_affinity_topk_f32": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_I), _I, _I, _I, _I,
                                   ctypes.POINTER(BlockExtras), _P]),
     "gn_packed_elems": (_SZ, [_I, _I]),

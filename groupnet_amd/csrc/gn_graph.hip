@@ -556,6 +556,121 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const float*
 }
 
 // --------------------------------------------------------------------------------------------
+// Exhaustive hyperedge search (init_adj_attention_listall, model/MS_HGNN_batch.py:390-414): hyperedge i =
+// the group of s agents containing i with the largest total affinity sum_{a,b in group} corr[a][b].
+// Candidates of agent i: i plus an (s-1)-subset of the others, in lexicographic order (the order of the
+// reference's torch.combinations table); the first maximum wins, NaN ranks above every number.
+// A workgroup owns a scene: corr and a binomial table live in LDS; for each agent the 256 threads stride
+// over the candidate ranks, un-rank each (combinatorial number system), score it from LDS and keep the
+// best; a workgroup arg-max picks the winner, which is un-ranked once more to write the 0/1 row.
+// --------------------------------------------------------------------------------------------
+constexpr unsigned long long kBinomCap = 1ull << 62;
+
+// members of candidate `rank` of agent i as a bit mask (N <= 64) and its score
+__device__ __forceinline__ unsigned long long listall_unrank(long long rank, int i, int n, int k, int ldb,
+                                                             const unsigned long long* __restrict__ binom,
+                                                             const float* __restrict__ s_corr, int N, float& score) {
+  unsigned long long mask = 1ull << i;
+  float sc = s_corr[i * N + i];
+  int x = 0;
+  for (int p = 0; p < k; ++p) {
+    for (; x < n - 1; ++x) {
+      const unsigned long long cnt = binom[(n - x - 1) * ldb + (k - p - 1)];   // candidates continuing with x here
+      if ((unsigned long long)rank < cnt) break;
+      rank -= (long long)cnt;
+    }
+    const int v = x < i ? x : x + 1;   // x-th of the other agents
+    ++x;
+    float add = s_corr[v * N + v];
+    unsigned long long m = mask;
+    while (m) {
+      const int u = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      add += s_corr[v * N + u] + s_corr[u * N + v];
+    }
+    sc += add;
+    mask |= 1ull << v;
+  }
+  score = sc;
+  return mask;
+}
+
+__device__ __forceinline__ bool listall_better(float a, long long ra, float b, long long rb) {
+  const bool an = a != a, bn = b != b;
+  if (an != bn) return an;
+  if (!an && a != b) return a > b;
+  return ra < rb;
+}
+
+__global__ __launch_bounds__(kBlock) void listall_incidence_kernel(const float* __restrict__ corr, float* __restrict__ H,
+                                                                   int N, int s, long long C) {
+  extern __shared__ __align__(16) float lds[];
+  const int n = N - 1, k = s - 1, ldb = k + 1;
+  unsigned long long* binom = reinterpret_cast<unsigned long long*>(lds);          // (n+1) x (k+1)
+  long long* s_rank = reinterpret_cast<long long*>(binom + (size_t)(n + 1) * ldb);  // kBlock/64 ranks
+  float* s_best = reinterpret_cast<float*>(s_rank + kBlock / 64);                  // 8 scores
+  float* s_corr = s_best + 8;                                                      // N x N
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int idx = tid; idx < N * N; idx += kBlock) s_corr[idx] = corr[(size_t)b * N * N + idx];
+  // Pascal's triangle, one column per thread, row by row (saturating: only ranks < C <= 2^31 are compared)
+  for (int r = 0; r <= n; ++r) {
+    if (tid <= k) {
+      unsigned long long v;
+      if (tid == 0) v = 1;
+      else if (r == 0) v = 0;
+      else {
+        v = binom[(r - 1) * ldb + tid - 1] + binom[(r - 1) * ldb + tid];
+        if (v > kBinomCap) v = kBinomCap;
+      }
+      binom[r * ldb + tid] = v;
+    }
+    __syncthreads();
+  }
+  for (int i = 0; i < N; ++i) {
+    float best = 0.f;
+    long long best_rank = -1;
+    for (long long rank = tid; rank < C; rank += kBlock) {
+      float sc;
+      listall_unrank(rank, i, n, k, ldb, binom, s_corr, N, sc);
+      if (best_rank < 0 || listall_better(sc, rank, best, best_rank)) {
+        best = sc;
+        best_rank = rank;
+      }
+    }
+    // wave arg-max, then across the waves
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(best, off, GN_WAVE);
+      const long long orank = __shfl_xor(best_rank, off, GN_WAVE);
+      if (orank >= 0 && (best_rank < 0 || listall_better(ob, orank, best, best_rank))) {
+        best = ob;
+        best_rank = orank;
+      }
+    }
+    if (lane == 0) {
+      s_best[wave] = best;
+      s_rank[wave] = best_rank;
+    }
+    __syncthreads();
+    best = s_best[0];
+    best_rank = s_rank[0];
+    for (int w = 1; w < kBlock / 64; ++w)
+      if (s_rank[w] >= 0 && (best_rank < 0 || listall_better(s_best[w], s_rank[w], best, best_rank))) {
+        best = s_best[w];
+        best_rank = s_rank[w];
+      }
+    float sc;
+    const unsigned long long mask = listall_unrank(best_rank, i, n, k, ldb, binom, s_corr, N, sc);
+    if (tid < N) H[((size_t)b * N + i) * N + tid] = (mask >> tid) & 1ull ? 1.f : 0.f;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_ones_kernel(float* __restrict__ p, long long n) {
+  for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < n; idx += (long long)gridDim.x * kBlock)
+    p[idx] = 1.f;
+}
+
+// --------------------------------------------------------------------------------------------
 // Philox4x32-10 uniforms
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void philox_uniform_kernel(float* __restrict__ U, unsigned long long n,
@@ -600,7 +715,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) 
 
 }  // namespace
 
-extern "C" int gn_abi_version(void) { return 15; }
+extern "C" int gn_abi_version(void) { return 16; }
 
 extern "C" const char* gn_strerror(int code) {
   switch (code) {
@@ -651,6 +766,32 @@ extern "C" int gn_topk_incidence_f32(const float* corr, float* const* H_list, co
   gn_allow_big_lds(topk_incidence_kernel);
   hipLaunchKernelGGL(topk_incidence_kernel, dim3((N + RB - 1) / RB, B), dim3(kBlock), (size_t)RB * N * sizeof(float),
                      (hipStream_t)stream, corr, sl, N, RB);
+  return gn_check_launch();
+}
+
+extern "C" int gn_listall_incidence_f32(const float* corr, float* H, int B, int N, int scale, gn_stream_t stream) {
+  GN_REQUIRE_PTR(corr);
+  GN_REQUIRE_PTR(H);
+  if (B <= 0 || N <= 0) return GN_ERR_SHAPE;
+  if (scale > N) return GN_ERR_K_RANGE;
+  hipStream_t st = (hipStream_t)stream;
+  if (scale == N) {   // one hyperedge holding every agent
+    const long long total = (long long)B * N;
+    hipLaunchKernelGGL(fill_ones_kernel, dim3(capped_grid(total, kBlock)), dim3(kBlock), 0, st, H, total);
+    return gn_check_launch();
+  }
+  const int s = scale < 1 ? 1 : scale;
+  if (N > 64) return GN_ERR_SHAPE;    // group membership is a 64-bit mask
+  // C(N-1, s-1) candidates per agent, bounded so that ranks and the search stay sane
+  long double c = 1;
+  for (int j = 1; j <= s - 1; ++j) c = c * (long double)(N - 1 - (s - 1) + j) / (long double)j;
+  if (c > 2147483647.0L) return GN_ERR_SHAPE;
+  const long long C = (long long)(c + 0.5L);
+  const size_t lds = (size_t)N * s * sizeof(unsigned long long) + (size_t)N * N * sizeof(float) + 8 * sizeof(float) +
+                     (kBlock / 64) * sizeof(long long);
+  if (lds > kLdsBudget) return GN_ERR_LDS;
+  if (lds > 64 * 1024) gn_allow_big_lds(listall_incidence_kernel);
+  hipLaunchKernelGGL(listall_incidence_kernel, dim3(B), dim3(kBlock), lds, st, corr, H, N, s, C);
   return gn_check_launch();
 }
 

@@ -112,6 +112,26 @@ def topk_incidence(corr: Tensor, scales: Sequence[int]) -> List[Tensor]:
     return Hs
 
 
+def listall_incidence(corr: Tensor, scale: int) -> Tensor:
+    """H of MS_HGNN_hyper.init_adj_attention_listall (model/MS_HGNN_batch.py:390-414): (B,1,N) of ones when
+    scale == N, else (B,N,N) with row i = the best group of max(scale,1) agents containing i (exhaustive
+    search over C(N-1, scale-1) candidates, first maximum in torch.combinations order)."""
+    _req(corr, "corr", (None, None, None))
+    B, N, N2 = corr.shape
+    if N != N2:
+        raise ValueError("corr must be (B, N, N)")
+    scale = int(scale)
+    if scale > N:
+        raise RuntimeError("group size larger than the number of agents")   # the reference cannot build its table either
+    H = torch.empty((B, 1 if scale == N else N, N), dtype=corr.dtype, device=corr.device)
+    if B == 0:
+        return H
+    with torch.cuda.device(corr.device):
+        check(load().gn_listall_incidence_f32(_ptr(corr), _ptr(H), B, N, scale, stream_handle()),
+              "gn_listall_incidence_f32")
+    return H
+
+
 def fused_affinity_fits(N: int, D: int, x_dim: int = 0) -> bool:
     """Whether one scene's tile of the fused affinity+top-k launch fits its 128 KiB LDS budget."""
     return N * (D + 4 + N + x_dim) * 4 <= 128 * 1024

@@ -64,6 +64,14 @@ int gn_affinity_f32(const float* f, float* corr, int B, int N, int D, gn_stream_
 int gn_topk_incidence_f32(const float* corr, float* const* H_list, const int* k_list, int n_scales,
                           int B, int N, gn_stream_t stream);
 
+/* A9: exhaustive hyperedge search — replaces MS_HGNN_hyper.init_adj_attention_listall,
+ * model/MS_HGNN_batch.py:390-414 (with its constant candidate table all_combs, :313-326, never
+ * materialised): scale == N -> H (B,1,N) all ones; else s = max(scale,1) and H (B,N,N) with row i = the
+ * group of s agents containing i that maximises sum_{a,b in group} corr[a][b] over all C(N-1,s-1)
+ * candidates (first maximum in the lexicographic candidate order of torch.combinations; NaN ranks first).
+ * N <= 64 and C(N-1,s-1) < 2^31, else GN_ERR_SHAPE; scale > N -> GN_ERR_K_RANGE. */
+int gn_listall_incidence_f32(const float* corr, float* H, int B, int N, int scale, gn_stream_t stream);
+
 /* A0+A1 fused: f -> corr (may be NULL: not written) and every H_s, without re-reading corr
  * from HBM.  Same contracts as the two functions above; N*(N+D)*4 bytes must fit in LDS.
  * `extras` (may be NULL) lets this first launch of a multiscale forward also produce what the

@@ -123,6 +123,43 @@ def topk_incidence_ranked(corr: Tensor, scale: int) -> Tensor:
     return (rank < k).to(corr.dtype)
 
 
+def listall_groups(N: int, group_size: int) -> Tensor:
+    """The constant candidate table of the exhaustive builder (MS_HGNN_batch.py:313-326, `all_combs`):
+    for every agent i, every group of `group_size` agents that contains i — i first, then a
+    (group_size-1)-subset of the others in lexicographic order (the order of torch.combinations).
+    Shape (N, C(N-1, group_size-1), group_size), int64."""
+    import itertools
+    rows = []
+    for i in range(N):
+        others = [a for a in range(N) if a != i]
+        rows.append([[i, *c] for c in itertools.combinations(others, group_size - 1)])
+    return torch.tensor(rows, dtype=torch.long)
+
+
+def listall_incidence(corr: Tensor, scale: int, like: Optional[Tensor] = None) -> Tensor:
+    """``MS_HGNN_hyper.init_adj_attention_listall`` (MS_HGNN_batch.py:390-414): hyperedge i = the group
+    of `scale` agents containing i whose affinity sub-matrix has the largest total (all ordered pairs,
+    diagonal included), searched exhaustively.  scale == N -> one all-ones edge.
+
+    Stated with the reference's own reduction ops on the same tensor shape ((B,N,C,s,s) contiguous,
+    torch.sum over the last two dims, torch.max over C), so score rounding and the tie rule (first
+    maximum) are the reference's; goldens are tie-free."""
+    B, N = corr.shape[0], corr.shape[1]
+    dtype = corr.dtype if like is None else like.dtype
+    if scale == N:
+        return torch.ones(B, 1, N, dtype=dtype)
+    s = max(int(scale), 1)
+    if s > N:
+        raise RuntimeError("group size larger than the number of agents")
+    groups = listall_groups(N, s)                                   # (N, C, s)
+    sub = corr[:, groups[:, :, :, None], groups[:, :, None, :]].contiguous()    # (B, N, C, s, s)
+    score = torch.sum(sub, dim=(3, 4))
+    _, best = torch.max(score, dim=2)                               # (B, N)
+    chosen = groups[torch.arange(N)[None, :], best]                 # (B, N, s)
+    H = torch.zeros(B, N, N, dtype=dtype)
+    return H.scatter(2, chosen, 1)
+
+
 def pairwise_incidence(N: int, B: int, dtype=torch.float32) -> Tensor:
     """``init_adj`` + ``H = rel_rec + rel_send`` (MS_HGNN_batch.py:143-160,118,124):
     edge e = i*N + j touches node j (rel_rec) and node i (rel_send); a

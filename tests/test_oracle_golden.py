@@ -142,3 +142,21 @@ def test_c_oracle_topk_ties_nan_range():
     for s in (1, 7, 39):
         rc, H = _c_topk(lib, big, s)
         assert np.array_equal(H, O.topk_incidence_ranked(torch.from_numpy(big), s).numpy())
+
+
+@pytest.mark.parametrize("name", ["n11_b6", "n7_b3", "n13_b2"])
+def test_listall_oracle_matches_reference_goldens(name):
+    """oracle.listall_incidence == the reference's init_adj_attention_listall (MS_HGNN_batch.py:390-414) on
+    fixtures produced by the reference method itself (tests/golden/make_golden_listall.py); every row's
+    winner leads the runner-up by >= 2e-4, far above fp32 summation noise."""
+    import numpy as np
+    import os
+    c = np.load(os.path.join(os.path.dirname(__file__), "golden", f"listall_{name}.npz"))
+    corr = torch.from_numpy(c["corr"])
+    for s in c["scales"]:
+        H = O.listall_incidence(corr, int(s))
+        assert torch.equal(H, torch.from_numpy(c[f"H_s{int(s)}"]))
+        if int(s) < corr.shape[1]:
+            assert float(H.sum(-1).min()) == float(H.sum(-1).max()) == float(max(int(s), 1))
+            assert bool((torch.diagonal(H, dim1=1, dim2=2) == 1).all())      # agent i is in its own group
+            assert float(c[f"margin_s{int(s)}"].min()) > 1e-4

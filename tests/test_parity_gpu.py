@@ -3,6 +3,8 @@ generated from the reference.  Needs an MI355X: `pytest -m gpu`.
 
 Bars (BASELINE.json north_star): top-k incidence H bit-identical; fp32 features within 1e-5 abs.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -683,3 +685,69 @@ def test_topk_heavy_ties_against_c_oracle():
         for s, H in zip(scales, Hs):
             rc, want = _c_topk(lib, corr, s)
             assert rc == 0 and np.array_equal(H.cpu().numpy(), want), (B, N, s)
+
+
+# ---- exhaustive hyperedge search (init_adj_attention_listall) -------------------------
+@pytest.mark.parametrize("name", ["n11_b6", "n7_b3", "n13_b2"])
+def test_listall_matches_reference_goldens(name):
+    from groupnet_amd import ops
+    import numpy as np
+    c = np.load(os.path.join(os.path.dirname(__file__), "golden", f"listall_{name}.npz"))
+    corr = torch.from_numpy(c["corr"]).to(dev())
+    for s in c["scales"]:
+        H = ops.listall_incidence(corr, int(s))
+        assert torch.equal(H.cpu(), torch.from_numpy(c[f"H_s{int(s)}"])), (name, int(s))
+
+
+@pytest.mark.parametrize("B,N,s", [(5, 11, 1), (4, 11, 10), (3, 12, 7), (2, 16, 8), (70, 11, 5), (3, 2, 1), (2, 20, 3)])
+def test_listall_matches_oracle(B, N, s):
+    """Scales the reference cannot even tabulate (torch.combinations with r = 9) and larger candidate
+    counts (C(15,7) = 6435), against the oracle's itertools statement of the same search."""
+    from groupnet_amd import ops
+    g = torch.Generator().manual_seed(1000 + 17 * N + s)
+    h = torch.randn(B, N, 64, generator=g)
+    corr = O.affinity(h)
+    H = ops.listall_incidence(corr.to(dev()), s)
+    assert torch.equal(H.cpu(), O.listall_incidence(corr, s))
+
+
+def test_listall_ties_first_candidate_wins():
+    """Small-integer affinities make every group total exact in fp32 whatever the summation order, so ties
+    are real ties: the kernel must resolve them like torch.max over the candidate axis (first maximum)."""
+    from groupnet_amd import ops
+    g = torch.Generator().manual_seed(77)
+    corr = torch.randint(0, 3, (6, 9, 9), generator=g).float()
+    corr = corr + corr.transpose(1, 2)
+    for s in (2, 3, 5, 8):
+        H = ops.listall_incidence(corr.to(dev()), s)
+        assert torch.equal(H.cpu(), O.listall_incidence(corr, s)), s
+    ones = torch.ones(2, 7, 7)
+    H = ops.listall_incidence(ones.to(dev()), 3).cpu()      # all tied: candidate 0 = i plus the two lowest others
+    for i in range(7):
+        want = sorted([i] + [a for a in range(7) if a != i][:2])
+        assert torch.nonzero(H[0, i]).flatten().tolist() == want
+
+
+def test_hyper_module_with_listall_builder():
+    """forward with `listall` set (model/MS_HGNN_batch.py:420-421) = the oracle forward on the oracle's
+    exhaustive-search incidence; scale > N is refused as by the reference's table builder."""
+    from groupnet_amd import ops
+    torch.manual_seed(41)
+    hyper = build_modules(1)[1]
+    hyper.listall = True
+    hyper.scale = 4
+    state = {k: v.detach().cpu().clone() for k, v in hyper.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    h = torch.randn(7, 11, 64, generator=g)
+    corr = O.affinity(h)
+    U = [torch.rand(7, 11, 10, generator=g)]
+    H_ref = O.listall_incidence(corr, 4)
+    nf_ref, fac_ref = O._message_passing(state, h, H_ref, U, 1, False, None)
+    hyper.to(dev())
+    with torch.no_grad():
+        nf, fac, H = hyper(h.to(dev()), corr.to(dev()), noise_u=[u.to(dev()) for u in U])
+    assert torch.equal(H.cpu(), H_ref)
+    assert float((nf.cpu() - nf_ref).abs().max()) <= 1e-5
+    assert float((fac.cpu() - fac_ref).abs().max()) <= 1e-5
+    with pytest.raises(RuntimeError):
+        ops.listall_incidence(corr.to(dev()), 12)
