@@ -9,8 +9,8 @@ this package is the ctypes binding plus the drop-in modules.  No CPU fallback ex
 from . import _lib, ops  # noqa: F401
 from .MS_HGNN_batch import (MLP, MLP_dict_softmax, MS_HGNN_hyper, MS_HGNN_oridinary, edge_aggregation,
                             set_noise_mode)
-from .past_encoder import PastEncoder, PositionalAgentEncoding
+from .past_encoder import FutureEncoder, PastEncoder, PositionalAgentEncoding
 
 __all__ = ["MLP", "MLP_dict_softmax", "MS_HGNN_hyper", "MS_HGNN_oridinary", "edge_aggregation", "ops",
-           "set_noise_mode", "PastEncoder", "PositionalAgentEncoding"]
+           "set_noise_mode", "PastEncoder", "FutureEncoder", "PositionalAgentEncoding"]
 __version__ = "0.1.0"

@@ -25,6 +25,29 @@ from .MS_HGNN_batch import MS_HGNN_hyper, MS_HGNN_oridinary, _needs_grad, run_me
 Tensor = torch.Tensor
 
 
+def multiscale_autograd(pair: MS_HGNN_oridinary, hypers: Sequence[MS_HGNN_hyper], scales: Sequence[int], f: Tensor,
+                        noise_u: Optional[Sequence] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """cat(f, pairwise(f), hyper_s(f, corr)...) and cat(H_s) with autograd attached: incidences from one fused
+    launch (constants of the backward), then ONE `MSHGNNFunction` node over all modules."""
+    from .backward import MSHGNNFunction
+    S = len(hypers)
+    fd = f.detach().contiguous()
+    if S and ops.fused_affinity_fits(fd.shape[1], fd.shape[2]):
+        _, Hs, new_H = ops.affinity_topk(fd, list(scales), want_corr=False, want_H_cat=True)
+    elif S:
+        Hs = ops.topk_incidence(ops.affinity(fd), list(scales))
+        new_H = torch.cat(Hs, dim=1)
+    else:
+        Hs, new_H = [], None
+    mods = (pair, *hypers)
+    nz = tuple(noise_u) if noise_u is not None else (None,) * (1 + S)
+    if len(nz) != 1 + S:
+        raise ValueError(f"noise_u: need {1 + S} entries (pairwise + one per scale)")
+    params = [p for m in mods for p in m.parameters()]
+    res = MSHGNNFunction.apply(mods, (None, *Hs), nz, *([f] * (1 + S)), *params)
+    return torch.cat([f, *res[0::2]], dim=-1), new_H
+
+
 class MultiScaleHGNN(nn.Module):
     """One pairwise module + one hyper module per scale on the same (f, corr).
 
@@ -72,20 +95,9 @@ class MultiScaleHGNN(nn.Module):
         if _needs_grad(self, f):
             # training: ONE autograd node for the 1+S modules (grouped fused forward, grouped HIP backward);
             # the concat is an ordinary differentiable torch.cat
-            from .backward import MSHGNNFunction
-            if S:
-                _, Hs, new_H = ops.affinity_topk(f.detach(), self.hyper_scales, want_corr=False, want_H_cat=True)
-            else:
-                Hs, new_H = [], None
             if advance:
                 ops.counter_add(advance[0], advance[1])
-            mods = (self.interaction, *self.interaction_hyper)
-            nz = tuple(noise_u) if noise_u is not None else (None,) * (1 + S)
-            if len(nz) != 1 + S:
-                raise ValueError(f"noise_u: need {1 + S} entries (pairwise + one per scale)")
-            params = [p for m in mods for p in m.parameters()]
-            res = MSHGNNFunction.apply(mods, (None, *Hs), nz, *([f] * (1 + S)), *params)
-            return torch.cat([f, *res[0::2]], dim=-1), new_H
+            return multiscale_autograd(self.interaction, list(self.interaction_hyper), self.hyper_scales, f, noise_u)
         if noise_u is None:
             # reference order: every draw of the pairwise module first, then scale by scale
             from .MS_HGNN_batch import _draw_uniform

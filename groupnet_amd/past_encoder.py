@@ -12,8 +12,10 @@ input_fc3 — contain no non-linearity, so they ARE one affine map per agent slo
     f[b,n] = M x[b,n] + c[n],   x = the T*in_dim raw inputs of the agent,
 M (64 x T*in_dim) and c (N x 64) composed once per parameter version in fp64.  That map is evaluated
 inside the affinity+top-k launch (`gn_affinity_topk_f32`, `extras.x_raw`), so the whole front-end costs
-no launch and f never makes an extra trip through HBM.  Training mode (dropout active) is not affine
-and is refused.
+no launch and f never makes an extra trip through HBM.  In training mode (dropout active, or gradients
+wanted) the embedding runs layer by layer on the HIP GEMM with its HIP backward, the modules through the
+autograd path of `groupnet_amd.backward`.  `FutureEncoder` is the same encoder at the
+reference's second call site plus its output head.
 
 Parity of this block is UNPINNED against the reference (GroupNet_nba.py cannot be imported in the build
 container; see oracle/past_encoder_oracle.py); it is tested against that restatement.
@@ -21,13 +23,13 @@ container; see oracle/past_encoder_oracle.py); it is tested against that restate
 from __future__ import annotations
 
 import math
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
 
 from . import ops
-from .MS_HGNN_batch import (MS_HGNN_hyper, MS_HGNN_oridinary, _check_forward_only, _draw_uniform, _param_key,
+from .MS_HGNN_batch import (MS_HGNN_hyper, MS_HGNN_oridinary, _draw_uniform, _needs_grad, _param_key,
                             run_message_passing)
 
 Tensor = torch.Tensor
@@ -51,30 +53,36 @@ class PositionalAgentEncoding(nn.Module):
         self.register_buffer('pe', pe)
 
 
-class PastEncoder(nn.Module):
-    def __init__(self, args, in_dim=4):
-        super().__init__()
+class _TrajectoryEncoder(nn.Module):
+    """What `PastEncoder` and `FutureEncoder` share (model/GroupNet_nba.py:198-286 and :316-413): the
+    embedding front-end, the pairwise module, up to three hyper modules, the concat."""
+
+    def _build_encoder(self, args, in_dim: int, length: int) -> None:
         self.args = args
         self.model_dim = args.hidden_dim
         self.scale_number = len(args.hyper_scales)
         if self.scale_number > 3:
-            raise ValueError("PastEncoder takes at most 3 hyper scales (model/GroupNet_nba.py:218-248); "
+            raise ValueError("the reference encoders take at most 3 hyper scales (model/GroupNet_nba.py:218-248); "
                              "use groupnet_amd.multiscale.MultiScaleHGNN for more")
         d = self.model_dim
         self.input_fc = nn.Linear(in_dim, d)
-        self.input_fc2 = nn.Linear(d * args.past_length, d)
+        self.input_fc2 = nn.Linear(d * length, d)
         self.input_fc3 = nn.Linear(d + 3, d)
         self.interaction = MS_HGNN_oridinary(embedding_dim=16, h_dim=d, mlp_dim=64, bottleneck_dim=d, batch_norm=0,
                                              nmp_layers=1)
         names = ["interaction_hyper", "interaction_hyper2", "interaction_hyper3"]
+        emb = self._hyper_embedding_dim
         for name, s in zip(names, args.hyper_scales):
-            setattr(self, name, MS_HGNN_hyper(embedding_dim=d, h_dim=d, mlp_dim=64, bottleneck_dim=d, batch_norm=0,
+            setattr(self, name, MS_HGNN_hyper(embedding_dim=emb, h_dim=d, mlp_dim=64, bottleneck_dim=d, batch_norm=0,
                                               nmp_layers=1, scale=s))
         self._hyper_names = names[:self.scale_number]
         self.pos_encoder = PositionalAgentEncoding(d, 0.1, concat=True)
+        self._length = length
         self._affine = None
 
-    # -- the embedding as one affine map ---------------------------------------------------------------
+    _hyper_embedding_dim = 64
+
+    # -- the embedding as one affine map (eval mode) ------------------------------------------------------
     def _front_params(self):
         return [self.input_fc.weight, self.input_fc.bias, self.input_fc2.weight, self.input_fc2.bias,
                 self.input_fc3.weight, self.input_fc3.bias, self.pos_encoder.fc.weight, self.pos_encoder.fc.bias]
@@ -101,38 +109,126 @@ class PastEncoder(nn.Module):
                     M[:, t * in_dim:(t + 1) * in_dim] = W3a @ W2t @ Wa @ Win
                     c0 = c0 + W2t @ (Wa @ b_in + Wb @ pe[t] + bfc)
                 c0 = W3a @ c0 + b3
-                cat = torch.zeros(N, 3, dtype=dd, device=Win.device)    # add_category, :252-264
-                cat[0:5, 0] = 1
-                cat[5:10, 1] = 1
-                cat[10, 2] = 1                                            # IndexError for N <= 10, as the reference
-                c = c0[None, :] + cat @ W3c.t()
+                c = c0[None, :] + self._category(N, dd, Win.device) @ W3c.t()
                 self._affine = (key, M.float().contiguous(), c.float().contiguous())
         return self._affine[1], self._affine[2]
 
-    def forward(self, inputs, batch_size, agent_num):
-        _check_forward_only(inputs)
-        if self.training and self.pos_encoder.dropout.p > 0:
-            raise RuntimeError("groupnet_amd.PastEncoder is inference-only: call .eval() (with dropout active the "
-                               "embedding is not the affine map the fused kernel evaluates)")
-        ops._req(inputs, "inputs", (batch_size * agent_num, None, self.input_fc.in_features))
-        B, N, D = batch_size, agent_num, self.model_dim
+    @staticmethod
+    def _category(N: int, dtype, device) -> Tensor:
+        """add_category (model/GroupNet_nba.py:252-264): team A, team B, ball one-hot by agent slot."""
+        cat = torch.zeros(N, 3, dtype=dtype, device=device)
+        cat[0:5, 0] = 1
+        cat[5:10, 1] = 1
+        cat[10, 2] = 1                                            # IndexError for N <= 10, as the reference
+        return cat
+
+    def _check_inputs(self, inputs: Tensor, B: int, N: int) -> int:
+        ops._req(inputs, "inputs", (B * N, None, self.input_fc.in_features))
         T = inputs.shape[1]
-        if T * D != self.input_fc2.in_features:
-            raise ValueError(f"inputs: {T} time steps, but input_fc2 was built for past_length={self.args.past_length}")
+        if T * self.model_dim != self.input_fc2.in_features:
+            raise ValueError(f"inputs: {T} time steps, but input_fc2 was built for {self._length}")
+        return T
+
+    def _embed_autograd(self, inputs: Tensor, B: int, N: int, T: int) -> Tensor:
+        """Lines 269-280 layer by layer (dropout active or gradients wanted): every Linear is the HIP GEMM with
+        its HIP backward (`hip_linear`); concat / dropout / views are torch glue."""
+        from .linear import hip_linear
+        D = self.model_dim
+        tf_in = hip_linear(inputs.reshape(B * N * T, -1), self.input_fc)                             # :269
+        pe = self.pos_encoder.pe[:T].to(inputs.dtype).repeat(B * N, 1)                               # :177-178
+        x = hip_linear(torch.cat([tf_in, pe], dim=-1), self.pos_encoder.fc)                          # :190-192
+        x = self.pos_encoder.dropout(x)                                                              # :195
+        ftraj = hip_linear(x.view(B * N, T * D), self.input_fc2)                                     # :276-277
+        cat = self._category(N, inputs.dtype, inputs.device).repeat(B, 1)                            # :262
+        return hip_linear(torch.cat((ftraj, cat), dim=-1), self.input_fc3).view(B, N, D)             # :279-280
+
+    def _encode(self, inputs: Tensor, B: int, N: int) -> Tuple[Tensor, Optional[Tensor]]:
+        """(final_feature (B,N,64*(2+S)), new_H): embedding, affinity, incidences, all modules, concat."""
+        T = self._check_inputs(inputs, B, N)
+        D, S = self.model_dim, self.scale_number
+        hypers = [getattr(self, n) for n in self._hyper_names]
+        scales = [m.scale for m in hypers]
+        dropout_on = self.training and self.pos_encoder.dropout.p > 0
+        if dropout_on or _needs_grad(self, inputs):
+            from .multiscale import multiscale_autograd
+            f = self._embed_autograd(inputs, B, N, T)
+            final, new_H = multiscale_autograd(self.interaction, hypers, scales, f)
+            return final, (new_H if S > 1 else None)
         M, c = self._compose(T, N)
         x_raw = inputs.reshape(B, N, T * inputs.shape[2])
-        S = self.scale_number
-        hypers = [getattr(self, n) for n in self._hyper_names]
         final = torch.empty((B, N, D * (2 + S)), dtype=inputs.dtype, device=inputs.device)
         cols = [final[..., D * (1 + i):D * (2 + i)] for i in range(1 + S)]
-        scales = [m.scale for m in hypers] or [N]     # the launch needs >= 1 scale; N = the cheap all-ones edge
-        _, Hs, new_H, f = ops.affinity_topk(None, scales, want_corr=False, f_out=final[..., :D],
-                                            want_H_cat=S > 1, embed=(x_raw, M, c))
-        if S == 0:
+        _, Hs, new_H, f = ops.affinity_topk(None, scales or [N], want_corr=False, f_out=final[..., :D],
+                                            want_H_cat=S > 1, embed=(x_raw, M, c))    # >= 1 scale per launch; N = the
+        if S == 0:                                                                     # cheap all-ones edge
             Hs, new_H = [], None
         elif S == 1:
             new_H = None      # the reference only builds new_H from two scales on (:296); its S==1 path raises
         mods = [self.interaction, *hypers]
         noise = [[_draw_uniform((B, N * N, 6), f.device)]] + [[_draw_uniform((B, H.shape[1], 10), f.device)] for H in Hs]
         run_message_passing(mods, [f] * (1 + S), [None, *Hs], noise, cols)
-        return final.view(B * N, -1), new_H
+        return final, new_H
+
+
+class PastEncoder(_TrajectoryEncoder):
+    def __init__(self, args, in_dim=4):
+        super().__init__()
+        self._build_encoder(args, in_dim, args.past_length)
+
+    def forward(self, inputs, batch_size, agent_num):
+        """-> (output_feature (B*N, 64*(2+S)), new_H).  Eval / no-grad: the fused path (the embedding is one
+        affine map evaluated inside the affinity launch).  Training (dropout active or gradients wanted): the
+        embedding layer by layer on the HIP GEMM, the modules through `MSHGNNFunction`."""
+        final, new_H = self._encode(inputs, batch_size, agent_num)
+        return final.view(batch_size * agent_num, -1), new_H
+
+
+class MLP2(nn.Module):
+    """Parameter container of the reference class (model/GroupNet_nba.py:128-150): Linear + activation per
+    hidden size; weights N(0, 0.01), biases 0 (model/utils.py:19-21)."""
+
+    def __init__(self, input_dim, hidden_dims=(128, 128), activation='tanh'):
+        super().__init__()
+        self.activation = {'tanh': torch.tanh, 'relu': torch.relu, 'sigmoid': torch.sigmoid}[activation]
+        self.out_dim = hidden_dims[-1]
+        self.affine_layers = nn.ModuleList()
+        last = input_dim
+        for nh in hidden_dims:
+            self.affine_layers.append(nn.Linear(last, nh))
+            last = nh
+        for m in self.affine_layers:
+            nn.init.normal_(m.weight, 0, 0.01)
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        from .linear import hip_linear
+        for affine in self.affine_layers:
+            x = self.activation(hip_linear(x, affine))
+        return x
+
+
+class FutureEncoder(_TrajectoryEncoder):
+    """Drop-in `FutureEncoder` (model/GroupNet_nba.py:316-438), the posterior q(z | past, future) of training
+    — SURVEY.md §8f rank 3: the same two modules at a second call site, after the same front-end, followed by
+    `out_mlp` and `qz_layer`.  `forward(inputs, batch_size, agent_num, past_feature)` -> q_z_params
+    (B*N, 2*zdim).  The reference unpacks the hyper modules' 3-tuples into two names (:408-413) and therefore
+    raises; this class does what those lines mean (take node_feat)."""
+
+    _hyper_embedding_dim = 16      # model/GroupNet_nba.py:339,350,361
+
+    def __init__(self, args, in_dim=4):
+        super().__init__()
+        self._build_encoder(args, in_dim, args.future_length)
+        scale_num = 2 + len(args.hyper_scales)
+        self.out_mlp = MLP2(scale_num * 2 * self.model_dim, [128], 'relu')
+        self.qz_layer = nn.Linear(self.out_mlp.out_dim, 2 * args.zdim)
+        nn.init.normal_(self.qz_layer.weight, 0, 0.01)
+        nn.init.constant_(self.qz_layer.bias, 0)
+
+    def forward(self, inputs, batch_size, agent_num, past_feature):
+        from .linear import hip_linear
+        final, _ = self._encode(inputs, batch_size, agent_num)
+        final = final.view(batch_size * agent_num, -1)
+        ops._req(past_feature, "past_feature", (batch_size * agent_num, final.shape[1]))
+        h = torch.cat((past_feature, final), dim=-1)                                                # :428
+        return hip_linear(self.out_mlp(h), self.qz_layer)                                           # :431-436

@@ -63,3 +63,32 @@ def embed_and_affinity(state: State, inputs: Tensor, batch_size: int, agent_num:
     f = embed(state, inputs, batch_size, agent_num)
     q = F.normalize(f, p=2, dim=2)
     return f, torch.matmul(q, q.permute(0, 2, 1))
+
+
+def encode(state: State, inputs: Tensor, batch_size: int, agent_num: int, scales, noise=None):
+    """Lines 269-311 (PastEncoder) / 395-425 (FutureEncoder), eval mode: embedding, affinity, the pairwise
+    module, one hyper module per scale, concat -> (final_feature (B*N, D*(2+S)), [H_s]).  `noise`: optional
+    list (pairwise first) of lists of uniforms; default draws from the global CPU generator in the
+    reference's call order."""
+    from . import ms_hgnn_oracle as O
+    B, N = batch_size, agent_num
+    f, corr = embed_and_affinity(state, inputs, B, N)
+    sub = lambda pre: {k[len(pre):]: v for k, v in state.items() if k.startswith(pre)}
+    draw = lambda i, shapes: noise[i] if noise is not None else [O.draw_uniform(s) for s in shapes]
+    inter, _ = O.ms_hgnn_pairwise_forward(sub("interaction."), f, draw(0, O.noise_shapes(B, N, None)), decomposed=True)
+    feats, Hs = [f, inter], []
+    for i, (name, s) in enumerate(zip(["interaction_hyper.", "interaction_hyper2.", "interaction_hyper3."], scales)):
+        nf, _, H = O.ms_hgnn_hyper_forward(sub(name), f, corr, s, draw(1 + i, O.noise_shapes(B, N, s)), decomposed=True)
+        feats.append(nf)
+        Hs.append(H)
+    return torch.cat(feats, dim=-1).view(B * N, -1), Hs
+
+
+def future_encoder_forward(state: State, inputs: Tensor, batch_size: int, agent_num: int, past_feature: Tensor,
+                           scales, noise=None) -> Tensor:
+    """`FutureEncoder.forward` (model/GroupNet_nba.py:393-438) with the 3-tuple unpack of :408-413 read as
+    "take node_feat": q_z_params = qz_layer(relu(out_mlp.affine_layers.0(cat(past_feature, final_feature))))."""
+    final, _ = encode(state, inputs, batch_size, agent_num, scales, noise)
+    h = torch.cat((past_feature, final), dim=-1)                                                              # :428
+    h = torch.relu(F.linear(h, state["out_mlp.affine_layers.0.weight"], state["out_mlp.affine_layers.0.bias"]))  # :431, MLP2 :147-150
+    return F.linear(h, state["qz_layer.weight"], state["qz_layer.bias"])                                     # :436
