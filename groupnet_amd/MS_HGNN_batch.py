@@ -157,24 +157,56 @@ class MLP_dict_softmax(nn.Module):
         self.init_MLP = MLP(input_dim=input_dim, output_dim=input_dim, hidden_size=hidden_size)
         self._pk: Optional[dict] = None
         self._pk_key = None
+        self._plan = None
 
     def _packed(self) -> dict:
-        key = _param_key(self.parameters())
-        if self._pk is None or key != self._pk_key:
-            with torch.no_grad():
-                K = self.bottleneck_dim
-                i0, i1 = _two_layer(self.init_MLP)
-                d0, d1 = _two_layer(self.MLP_distribution)
-                f0, f1 = _two_layer(self.MLP_factor)
-                Wd1 = torch.zeros(32, 256, dtype=d1.weight.dtype, device=d1.weight.device)
-                Wd1[:K, :128] = d1.weight
-                Wd1[K, 128:] = f1.weight[0]
-                bd1 = torch.zeros(32, dtype=d1.bias.dtype, device=d1.bias.device)
-                bd1[:K] = d1.bias
-                bd1[K] = f1.bias[0]
-                self._pk = dict(
-                    W=ops.edge_stream(i0.weight, i1.weight, torch.cat((d0.weight, f0.weight), 0), Wd1),
-                    bias=ops.bias_stream([i0.bias, i1.bias, torch.cat((d0.bias, f0.bias), 0), bd1]))
+        """Weight stream of the edge-MLP kernel (layout: `ops.edge_stream`) and its biases, refreshed from the
+        parameters by one `PackPlan` launch whenever they changed."""
+        params = list(self.parameters())
+        if self._plan is None or self._plan[0] != tuple(p.data_ptr() for p in params):
+            K = self.bottleneck_dim
+            i0, i1 = _two_layer(self.init_MLP)
+            d0, d1 = _two_layer(self.MLP_distribution)
+            f0, f1 = _two_layer(self.MLP_factor)
+            plan, T = ops.PackPlan(params[0].device), ops.PackPlan.TILE
+            w0 = plan.alloc(0)
+            a0 = lambda o: plan.block(plan.alloc(2 * T), i0.weight, 2, r0=32 * o, rows=32)         # hidden tile o of layer 0
+            b0 = lambda o: plan.block(plan.alloc(2 * T), (d0 if o < 4 else f0).weight, 2, r0=32 * (o % 4), rows=32)
+
+            def sa(t):      # both output tiles of init_MLP layer 1 over hidden tile t
+                off = plan.alloc(2 * T)
+                for o in range(2):
+                    plan.block(off + o * T, i1.weight, 1, r0=32 * o, c0=32 * t, rows=32, cols=32)
+
+            def sb(t):      # (logits | factor) head over hidden tile t: d1 rows 0..K-1, f1 row K
+                off = plan.alloc(T)
+                if t < 4:
+                    plan.block(off, d1.weight, 1, c0=32 * t, cols=32)
+                else:
+                    plan.block(off, f1.weight, 1, c0=32 * (t - 4), cols=32, place_r=K)
+            # pair A: T0 T1 S0 T2 S1 T3 S2 S3; pair B: T0 T1 S0 T2 S1 ... T7 S6 S7; then the ring's 8-step run-out
+            a0(0), a0(1), sa(0), a0(2), sa(1), a0(3), sa(2), sa(3)
+            b0(0), b0(1)
+            for t in range(8):
+                sb(t)
+                if t < 6:
+                    b0(t + 2)
+            plan.alloc(2 * T)
+            w_len = plan.size - w0
+            bo = plan.alloc(128 + 64 + 256 + 32)
+            plan.vector(bo, i0.bias)
+            plan.vector(bo + 128, i1.bias)
+            plan.vector(bo + 192, d0.bias)
+            plan.vector(bo + 320, f0.bias)
+            plan.vector(bo + 448, d1.bias)
+            plan.vector(bo + 448, f1.bias, place=K)
+            plan.finish()
+            self._plan = (plan.sources[:0] + tuple(p.data_ptr() for p in params), plan)
+            self._pk = dict(W=plan.view(w0, w_len), bias=plan.view(bo, 480))
+            self._pk_key = None
+        key = _param_key(params)
+        if key != self._pk_key:
+            self._plan[1].refresh()
             self._pk_key = key
         return self._pk
 
@@ -203,24 +235,43 @@ class edge_aggregation(nn.Module):
         self.mlp = MLP(input_dim=input_dim, output_dim=input_dim, hidden_size=(128,))  # unused, kept for state_dict
         self._pk: Optional[dict] = None
         self._pk_key = None
+        self._plan = None
 
     def _packed(self) -> dict:
-        key = _param_key(self.agg_mlp.parameters())
-        if self._pk is None or key != self._pk_key:
-            with torch.no_grad():
-                l0 = [m.layers[0] for m in self.agg_mlp]
-                l1 = [m.layers[1] for m in self.agg_mlp]
-                # pairwise form: layer 1 of all types as one (K*128 x 64) matrix applied per node (half the
-                # bias rides with each of the two nodes of a pair); layer 2 re-ordered hidden-tile-major
-                w2t = [ops.pack_linear(l.weight.detach().contiguous()).view(2, 4, 4, 256).permute(1, 0, 2, 3).reshape(-1)
-                       for l in l1]
-                self._pk = dict(
-                    W=ops.pack_stream([w for a, b in zip(l0, l1) for w in (a.weight, b.weight)]),
-                    b1=torch.stack([l.bias.detach() for l in l0]).contiguous(),
-                    b2=torch.stack([l.bias.detach() for l in l1]).contiguous(),
-                    W1cat=ops.pack_linear(torch.cat([l.weight.detach() for l in l0], 0).contiguous()),
-                    b1half=(torch.cat([l.bias.detach() for l in l0]) * 0.5).contiguous(),
-                    W2t=torch.cat(w2t).contiguous())
+        """Packed images of the K typed MLPs, refreshed by one `PackPlan` launch whenever they changed:
+        W (both layers, type by type), b1 / b2, and for the pairwise form layer 1 of all types as one
+        (K*128 x 64) matrix applied per node (half the bias rides with each of the two nodes of a pair) and
+        layer 2 re-ordered hidden-tile-major."""
+        params = list(self.agg_mlp.parameters())
+        if self._plan is None or self._plan[0] != tuple(p.data_ptr() for p in params):
+            K = self.edge_types
+            l0 = [m.layers[0] for m in self.agg_mlp]
+            l1 = [m.layers[1] for m in self.agg_mlp]
+            plan, T = ops.PackPlan(params[0].device), ops.PackPlan.TILE
+            w0 = plan.alloc(0)
+            for a, b in zip(l0, l1):
+                plan.matrix(a.weight)
+                plan.matrix(b.weight)
+            w_len = plan.size - w0
+            b1o, b2o, bho = plan.alloc(K * 128), plan.alloc(K * 64), plan.alloc(K * 128)
+            w1c, w2t = plan.alloc(K * 8 * T), plan.alloc(K * 8 * T)
+            for k in range(K):
+                plan.vector(b1o + 128 * k, l0[k].bias)
+                plan.vector(b2o + 64 * k, l1[k].bias)
+                plan.vector(bho + 128 * k, l0[k].bias, scale=0.5)
+                plan.block(w1c + k * 8 * T, l0[k].weight, 2)
+                for t in range(4):
+                    for o in range(2):
+                        plan.block(w2t + (k * 8 + t * 2 + o) * T, l1[k].weight, 1, r0=32 * o, c0=32 * t, rows=32, cols=32)
+            plan.finish()
+            self._plan = (tuple(p.data_ptr() for p in params), plan)
+            self._pk = dict(W=plan.view(w0, w_len), b1=plan.view(b1o, K * 128).view(K, 128),
+                            b2=plan.view(b2o, K * 64).view(K, 64), W1cat=plan.view(w1c, K * 8 * T),
+                            b1half=plan.view(bho, K * 128), W2t=plan.view(w2t, K * 8 * T))
+            self._pk_key = None
+        key = _param_key(params)
+        if key != self._pk_key:
+            self._plan[1].refresh()
             self._pk_key = key
         return self._pk
 
@@ -243,16 +294,17 @@ def _param_key(params: Iterable[nn.Parameter]):
 
 
 def invalidate_weight_caches(module: nn.Module) -> None:
-    """Drop every packed / concatenated weight image below `module`.  They are keyed on the parameters'
+    """Mark every packed / concatenated weight image below `module` stale.  They are keyed on the parameters'
     (address, in-place version); anything that rewrites parameters behind autograd's back — a replayed
-    hipGraph containing the optimizer step — must call this before the next eager use."""
+    hipGraph containing the optimizer step — must call this before the next eager use.  (The pack plans
+    themselves — arenas and segment tables — stay; the next use re-runs their one refresh launch.)"""
     for m in module.modules():
         d = m.__dict__
-        if "_pk" in d:
-            m._pk, m._pk_key = None, None
+        if "_pk_key" in d:
+            m._pk_key = None
         for name in ("_pk_n2e", "_pk_mlp"):
-            if name in d:
-                d[name].clear()
+            for hit in d.get(name, {}).values():
+                hit[3] = None
         d.pop("_bwd_cat", None)
         if "_affine" in d:
             m._affine = None
@@ -287,40 +339,64 @@ class _MessagePassing(nn.Module):
         self.edge_aggregation_list = nn.ModuleList(
             edge_aggregation(input_dim=h_dim, output_dim=bottleneck_dim, hidden_size=(128,), edge_types=K)
             for _ in range(nmp_layers))
-        self._pk_n2e: Dict[int, Tuple[tuple, dict]] = {}
-        self._pk_mlp: Dict[int, Tuple[tuple, dict]] = {}
+        self._pk_n2e: Dict[int, list] = {}      # idx -> [param addresses, packed dict, PackPlan, version key]
+        self._pk_mlp: Dict[int, list] = {}
 
     # -- packed weights ------------------------------------------------------------------------
     def _packed_n2e(self, idx: int) -> dict:
         start, att = self.node2edge_start_mlp[idx], self.attention_mlp[idx]
-        key = _param_key(list(start.parameters()) + list(att.parameters()))
+        params = list(start.parameters()) + list(att.parameters())
+        ptrs = tuple(p.data_ptr() for p in params)
         hit = self._pk_n2e.get(idx)
-        if hit is None or hit[0] != key:
-            with torch.no_grad():
-                s0, s1 = _two_layer(start)
-                a0, a1 = _two_layer(att)
-                D = _HDIM_EXTEND
-                # attention layer 0 acts on cat(x'_n, e0_e): split it into the node half (with the
-                # bias) and the edge half, which by linearity is applied to x' before the H-pooling
-                Wpq = torch.cat((a0.weight[:, :D], a0.weight[:, D:]), 0).contiguous()
-                bpq = torch.cat((a0.bias, torch.zeros_like(a0.bias)), 0).contiguous()
-                pk = dict(W=ops.pack_stream([s0.weight, s1.weight, Wpq]),
-                          bias=ops.bias_stream([s0.bias, s1.bias, bpq]),
-                          w2=a1.weight.detach()[0], b2=a1.bias.detach())    # views of the parameters: no host sync
-            self._pk_n2e[idx] = (key, pk)
-            hit = self._pk_n2e[idx]
+        if hit is None or hit[0] != ptrs:
+            s0, s1 = _two_layer(start)
+            a0, a1 = _two_layer(att)
+            D = _HDIM_EXTEND
+            plan = ops.PackPlan(params[0].device)
+            w0 = plan.matrix(s0.weight)
+            plan.matrix(s1.weight)
+            # attention layer 0 acts on cat(x'_n, e0_e): split it into the node half (with the bias) and the
+            # edge half, which by linearity is applied to x' before the H-pooling: Wpq = [W[:, :D]; W[:, D:]]
+            wpq = plan.alloc(4 * plan.TILE)
+            plan.block(wpq, a0.weight, 2, c0=0, cols=D)
+            plan.block(wpq, a0.weight, 2, c0=D, cols=D, place_r=32)
+            w_len = plan.size - w0
+            bo = plan.alloc(256 + 64 + 64)
+            plan.vector(bo, s0.bias)
+            plan.vector(bo + 256, s1.bias)
+            plan.vector(bo + 320, a0.bias)
+            plan.finish()
+            pk = dict(W=plan.view(w0, w_len), bias=plan.view(bo, 384),
+                      w2=a1.weight.detach()[0], b2=a1.bias.detach())    # views of the parameters: no host sync
+            hit = self._pk_n2e[idx] = [ptrs, pk, plan, None]
+        key = _param_key(params)
+        if key != hit[3]:
+            hit[2].refresh()
+            hit[3] = key
         return hit[1]
 
     def _packed_mlp2(self, mlp: MLP) -> dict:
-        key = _param_key(mlp.parameters())
+        params = list(mlp.parameters())
+        ptrs = tuple(p.data_ptr() for p in params)
         hit = self._pk_mlp.get(id(mlp))
-        if hit is None or hit[0] != key:
-            with torch.no_grad():
-                l0, l1 = _two_layer(mlp)
-                pk = dict(W=ops.pack_stream([l0.weight, l1.weight]), bias=ops.bias_stream([l0.bias, l1.bias]),
-                          din=l0.in_features, dh=l0.out_features, dout=l1.out_features)
-            self._pk_mlp[id(mlp)] = (key, pk)
-            hit = self._pk_mlp[id(mlp)]
+        if hit is None or hit[0] != ptrs:
+            l0, l1 = _two_layer(mlp)
+            plan = ops.PackPlan(params[0].device)
+            w0 = plan.matrix(l0.weight)
+            plan.matrix(l1.weight)
+            w_len = plan.size - w0
+            pad = lambda n: (n + 31) // 32 * 32
+            bo = plan.alloc(pad(l0.out_features) + pad(l1.out_features))
+            plan.vector(bo, l0.bias)
+            plan.vector(bo + pad(l0.out_features), l1.bias)
+            plan.finish()
+            pk = dict(W=plan.view(w0, w_len), bias=plan.view(bo, pad(l0.out_features) + pad(l1.out_features)),
+                      din=l0.in_features, dh=l0.out_features, dout=l1.out_features)
+            hit = self._pk_mlp[id(mlp)] = [ptrs, pk, plan, None]
+        key = _param_key(params)
+        if key != hit[3]:
+            hit[2].refresh()
+            hit[3] = key
         return hit[1]
 
     # -- stages (single-module faces of the grouped engine below) -----------------------------------

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -61,6 +61,11 @@ class BlockExtras(ctypes.Structure):    # gn_block_extras_t
                 ("x_raw", _P), ("x_dim", _I), ("M", _P), ("c", _P), ("f_contig", _P)]
 
 
+class PackSeg(ctypes.Structure):       # gn_pack_seg_t
+    _fields_ = [("src", _P), ("dst", _P), ("ld", _I), ("rows", _I), ("cols", _I), ("place_r", _I), ("place_c", _I),
+                ("IT", _I), ("scale", _F), ("_pad", _I)]
+
+
 class GemmDesc(ctypes.Structure):      # gn_gemm_desc_t
     _fields_ = [("A", _P), ("B", _P), ("C", _P), ("bias", _P), ("mask", _P), ("rs", _P), ("colsum", _P),
                 ("M", _I), ("N", _I), ("K", _I), ("lda", _I), ("ldb", _I), ("ldc", _I), ("ldmask", _I), ("rs_ld", _I),
@@ -81,6 +86,7 @@ SIGNATURES = {
                                   ctypes.POINTER(BlockExtras), _P]),
     "gn_packed_elems": (_SZ, [_I, _I]),
     "gn_pack_linear_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "gn_pack_segments_f32": (_I, [_P, _I, _I, _P]),
     "gn_node_mlp_f32": (_I, [ctypes.POINTER(NodeGroup), _I, _I, _P]),
     "gn_node2edge_f32": (_I, [ctypes.POINTER(N2EGroup), _I, _I, _I, _P]),
     "gn_edge_mlp_gumbel_f32": (_I, [ctypes.POINTER(EdgeGroup), _I, _F, _U64, _P, _P]),

@@ -50,6 +50,27 @@ __global__ void pack_linear_kernel(const float* __restrict__ W, float* __restric
   }
 }
 
+// Many weights, one launch.  A segment drops a source block (rows x cols, row-major, ld) into a packed
+// image at (place_r, place_c) of the image's virtual matrix — or, IT == 0, copies a vector — scaled.  The
+// table lives in DEVICE memory: it is built once per module and parameter addresses, after which refreshing
+// every packed weight of the module after an optimizer step is one fill + this one launch (and capturable).
+__global__ __launch_bounds__(256) void pack_segments_kernel(const gn_pack_seg_t* __restrict__ segs) {
+  const gn_pack_seg_t S = segs[blockIdx.y];
+  const int total = S.rows * S.cols;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int r = idx / S.cols, c = idx - r * S.cols;
+    const float v = S.scale * S.src[(size_t)r * S.ld + c];
+    const int row = S.place_r + r, col = S.place_c + c;
+    if (S.IT == 0) {
+      S.dst[col] = v;
+    } else {
+      const int o = row >> 5, t = col >> 5, cc = col & 31;
+      const int lane = (row & 31) + 32 * ((cc & 7) >> 2);
+      S.dst[((((size_t)o * S.IT + t) * 4 + (cc >> 3)) * 64 + lane) * 4 + (cc & 3)] = v;
+    }
+  }
+}
+
 // ---- register-resident building blocks -----------------------------------------------------
 template <int IT>
 __device__ __forceinline__ void load_rows(const float* __restrict__ X, int ld, int row, int h, f32x16 (&a)[IT]) {
@@ -948,6 +969,15 @@ extern "C" int gn_pack_linear_f32(const float* W, float* Wp, int out_features, i
   const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
   hipLaunchKernelGGL(pack_linear_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, Wp, out_features,
                      in_features, ld, col_offset, OT, IT);
+  return gn_check_launch();
+}
+
+extern "C" int gn_pack_segments_f32(const gn_pack_seg_t* segs_dev, int n_segs, int max_elems, gn_stream_t stream) {
+  GN_REQUIRE_PTR(segs_dev);
+  if (n_segs < 1 || n_segs > 65535 || max_elems < 1) return GN_ERR_SHAPE;
+  int gx = (max_elems + 255) / 256;
+  gx = gx > 16 ? 16 : gx;
+  hipLaunchKernelGGL(pack_segments_kernel, dim3(gx, n_segs), dim3(256), 0, (hipStream_t)stream, segs_dev);
   return gn_check_launch();
 }
 

@@ -241,6 +241,80 @@ def bias_stream(biases: Sequence[Tensor]) -> Tensor:
     return torch.cat(parts).contiguous()
 
 
+class PackPlan:
+    """All packed weight images of one module as ONE arena refreshed by ONE launch.
+
+    Built once (per module and parameter addresses): `matrix` / `block` / `vector` record segments of
+    `gn_pack_segments_f32` and hand out arena offsets; `finish()` uploads the segment table to the device.
+    `refresh()` = zero the arena + one kernel launch, reading the parameters in place — what has to happen
+    after every optimizer step, capturable in a hipGraph."""
+
+    TILE = 1024
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.size = 0
+        self._segs: List[tuple] = []
+        self._keep: List[Tensor] = []
+        self.arena: Optional[Tensor] = None
+        self.table: Optional[Tensor] = None
+        self.max_elems = 1
+
+    def alloc(self, numel: int) -> int:
+        off = self.size
+        self.size += (numel + 63) // 64 * 64          # keeps every image 256-byte aligned
+        return off
+
+    def block(self, dst_off: int, W: Tensor, IT: int, r0=0, c0=0, rows=None, cols=None, place_r=0, place_c=0,
+              scale=1.0) -> None:
+        """W[r0:r0+rows, c0:c0+cols] -> the packed image at arena offset dst_off (IT tiles per packed row),
+        at (place_r, place_c) of its virtual matrix."""
+        W = W.detach()
+        if W.dim() != 2 or W.stride(1) != 1 or W.dtype != torch.float32 or W.device != self.device:
+            raise ValueError("PackPlan.block: 2-D fp32 row-major matrix on the plan's device")
+        rows = W.shape[0] - r0 if rows is None else rows
+        cols = W.shape[1] - c0 if cols is None else cols
+        self._keep.append(W)
+        self._segs.append((W.data_ptr() + 4 * (r0 * W.stride(0) + c0), dst_off, W.stride(0), rows, cols, place_r, place_c,
+                           IT, scale))
+        self.max_elems = max(self.max_elems, rows * cols)
+
+    def matrix(self, W: Tensor) -> int:
+        """The whole (out x in) weight as a standard packed image; returns its arena offset."""
+        OT, IT = (W.shape[0] + 31) // 32, (W.shape[1] + 31) // 32
+        off = self.alloc(OT * IT * self.TILE)
+        self.block(off, W, IT)
+        return off
+
+    def vector(self, dst_off: int, v: Tensor, place=0, scale=1.0) -> None:
+        v = v.detach().reshape(1, -1)
+        if v.stride(1) != 1 or v.dtype != torch.float32 or v.device != self.device:
+            raise ValueError("PackPlan.vector: contiguous fp32 vector on the plan's device")
+        self._keep.append(v)
+        self._segs.append((v.data_ptr(), dst_off, v.shape[1], 1, v.shape[1], 0, place, 0, scale))
+        self.max_elems = max(self.max_elems, v.shape[1])
+
+    def finish(self) -> "PackPlan":
+        self.arena = torch.zeros(max(self.size, 64), dtype=torch.float32, device=self.device)
+        base = self.arena.data_ptr()
+        arr = (_lib.PackSeg * len(self._segs))()
+        for i, (src, off, ld, rows, cols, pr, pc, IT, scale) in enumerate(self._segs):
+            arr[i] = _lib.PackSeg(src, base + 4 * off, ld, rows, cols, pr, pc, IT, float(scale), 0)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = raw.to(self.device)
+        self.sources = tuple(t.data_ptr() for t in self._keep)
+        return self
+
+    def view(self, off: int, numel: int) -> Tensor:
+        return self.arena[off:off + numel]
+
+    def refresh(self) -> None:
+        self.arena.zero_()
+        with torch.cuda.device(self.device):
+            check(load().gn_pack_segments_f32(_ptr(self.table), len(self._segs), self.max_elems, stream_handle()),
+                  "gn_pack_segments_f32")
+
+
 def _groups(n: int) -> None:
     if not 1 <= n <= _lib.MAX_GROUPS:
         raise ValueError(f"1..{_lib.MAX_GROUPS} groups per launch, got {n}")

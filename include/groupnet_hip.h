@@ -111,6 +111,21 @@ size_t gn_packed_elems(int out_features, int in_features);
 int gn_pack_linear_f32(const float* W, float* Wp, int out_features, int in_features, int ld,
                        int col_offset, gn_stream_t stream);
 
+/* Many weights in one launch: segment i drops the source block src (rows x cols, row-major, ld) scaled by
+ * `scale` into the packed image starting at dst, at (place_r, place_c) of the image's virtual matrix whose
+ * packed rows hold IT 32-column tiles (the layout of gn_pack_linear_f32); IT == 0 copies a vector instead:
+ * dst[place_c + j] = scale * src[j].  Nothing outside the block is written: zero the destination first.
+ * `segs` is a DEVICE array (built once per module; the refresh after an optimizer step is then one fill +
+ * one launch, capturable in a hipGraph); max_elems = the largest rows*cols of any segment. */
+typedef struct {
+  const float* src;
+  float* dst;
+  int ld, rows, cols, place_r, place_c, IT;
+  float scale;
+  int _pad;
+} gn_pack_seg_t;
+int gn_pack_segments_f32(const gn_pack_seg_t* segs, int n_segs, int max_elems, gn_stream_t stream);
+
 /* ---- grouped launches --------------------------------------------------------------------
  * The 1+S modules of one multiscale forward (pairwise + one hyper module per scale) are
  * independent and differ only in weights, incidence and edge count.  Every stage below

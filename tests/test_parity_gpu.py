@@ -751,3 +751,53 @@ def test_hyper_module_with_listall_builder():
     assert float((fac.cpu() - fac_ref).abs().max()) <= 1e-5
     with pytest.raises(RuntimeError):
         ops.listall_incidence(corr.to(dev()), 12)
+
+
+def test_pack_plan_equals_matrix_by_matrix_packing():
+    """The one-launch refresh of a module's packed weights (`ops.PackPlan`, gn_pack_segments_f32) writes
+    bit for bit what packing matrix by matrix (gn_pack_linear_f32 + concatenation) produces — for the node,
+    edge, typed-aggregation and closing MLP streams — and follows in-place parameter updates."""
+    from groupnet_amd import ops
+    torch.manual_seed(17)
+    pair, hyper = build_modules(2)
+    for m in (pair.to(dev()), hyper.to(dev())):
+        K = m.edge_types
+        for rnd in range(2):
+            s0, s1 = m.node2edge_start_mlp[1].layers
+            a0, a1 = m.attention_mlp[1].layers
+            pk = m._packed_n2e(1)
+            Wpq = torch.cat((a0.weight[:, :64], a0.weight[:, 64:]), 0).detach().contiguous()
+            bpq = torch.cat((a0.bias, torch.zeros_like(a0.bias)), 0).detach()
+            assert torch.equal(pk["W"], ops.pack_stream([s0.weight, s1.weight, Wpq]))
+            assert torch.equal(pk["bias"], ops.bias_stream([s0.bias, s1.bias, bpq]))
+            st = m.nmp_mlps[1]
+            i0, i1 = st.init_MLP.layers
+            d0, d1 = st.MLP_distribution.layers
+            f0, f1 = st.MLP_factor.layers
+            Wd1 = torch.zeros(32, 256, device=dev())
+            Wd1[:K, :128] = d1.weight.detach()
+            Wd1[K, 128:] = f1.weight.detach()[0]
+            bd1 = torch.zeros(32, device=dev())
+            bd1[:K] = d1.bias.detach()
+            bd1[K] = f1.bias.detach()[0]
+            pk = st._packed()
+            assert torch.equal(pk["W"], ops.edge_stream(i0.weight, i1.weight, torch.cat((d0.weight, f0.weight), 0).detach(), Wd1))
+            assert torch.equal(pk["bias"], ops.bias_stream([i0.bias, i1.bias, torch.cat((d0.bias, f0.bias), 0), bd1]))
+            agg = m.edge_aggregation_list[0]
+            l0 = [x.layers[0] for x in agg.agg_mlp]
+            l1 = [x.layers[1] for x in agg.agg_mlp]
+            pk = agg._packed()
+            assert torch.equal(pk["W"], ops.pack_stream([w for a, b in zip(l0, l1) for w in (a.weight, b.weight)]))
+            assert torch.equal(pk["b1"], torch.stack([l.bias.detach() for l in l0]))
+            assert torch.equal(pk["b2"], torch.stack([l.bias.detach() for l in l1]))
+            assert torch.equal(pk["W1cat"], ops.pack_linear(torch.cat([l.weight.detach() for l in l0], 0).contiguous()))
+            assert torch.equal(pk["b1half"], torch.cat([l.bias.detach() for l in l0]) * 0.5)
+            w2t = [ops.pack_linear(l.weight.detach().contiguous()).view(2, 4, 4, 256).permute(1, 0, 2, 3).reshape(-1) for l in l1]
+            assert torch.equal(pk["W2t"], torch.cat(w2t))
+            e0, e1 = m.nmp_mlp_end.layers
+            pk = m._packed_mlp2(m.nmp_mlp_end)
+            assert torch.equal(pk["W"], ops.pack_stream([e0.weight, e1.weight]))
+            assert torch.equal(pk["bias"], ops.bias_stream([e0.bias, e1.bias]))
+            with torch.no_grad():          # in-place update (an optimizer step): the next access re-packs
+                for p in m.parameters():
+                    p.add_(torch.randn_like(p) * 0.1)
