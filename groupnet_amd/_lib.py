@@ -72,7 +72,7 @@ class GemmDesc(ctypes.Structure):      # gn_gemm_desc_t
                 ("flags", _I), ("alpha", _F), ("beta", _F)]
 
 
-GEMM_TRANS_A, GEMM_TRANS_B, GEMM_RELU, GEMM_ACCUM = 1, 2, 4, 8
+GEMM_TRANS_A, GEMM_TRANS_B, GEMM_RELU, GEMM_ACCUM, GEMM_TRANS_C = 1, 2, 4, 8, 16
 MAX_GROUPS = 10
 
 # name -> (restype, argtypes); mirrors include/groupnet_hip.h one to one

@@ -49,20 +49,22 @@ class GemmBatch:
         self.device = None
 
     def add(self, A: Tensor, Bm: Tensor, C: Tensor, tA=False, tB=False, bias=None, mask=None, relu=False, alpha=1.0,
-            beta=0.0, rs: Optional[Tensor] = None, colsum: Optional[Tensor] = None, accum=False) -> Tensor:
+            beta=0.0, rs: Optional[Tensor] = None, colsum: Optional[Tensor] = None, accum=False, tC=False) -> Tensor:
         for t in (A, Bm, C) + ((mask,) if mask is not None else ()):
             if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or t.dtype != torch.float32:
                 raise ValueError("gemm: 2-D fp32 views with unit column stride")
         M, K = (A.shape[1], A.shape[0]) if tA else (A.shape[0], A.shape[1])
         K2, N = (Bm.shape[1], Bm.shape[0]) if tB else (Bm.shape[0], Bm.shape[1])
-        if K != K2 or tuple(C.shape) != (M, N) or (mask is not None and tuple(mask.shape) != (M, N)):
+        if K != K2 or tuple(C.shape) != ((N, M) if tC else (M, N)) or (mask is not None and tuple(mask.shape) != (M, N)):
             raise ValueError(f"gemm: ({M},{K}) x ({K2},{N}) -> {tuple(C.shape)}")
         if rs is not None and (rs.dim() != 1 or rs.shape[0] != A.shape[0]):
             raise ValueError("gemm: rs scales the stored rows of A")
         if colsum is not None and (not tA or colsum.numel() != M or not colsum.is_contiguous()):
             raise ValueError("gemm: colsum needs transA and M contiguous entries")
         flags = (_lib.GEMM_TRANS_A if tA else 0) | (_lib.GEMM_TRANS_B if tB else 0) | \
-                (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_ACCUM if accum else 0)
+                (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_ACCUM if accum else 0) | (_lib.GEMM_TRANS_C if tC else 0)
+        if tC and not accum:
+            raise ValueError("gemm: tC (write the product transposed) exists for accumulate mode only")
         ld = lambda t: max(t.stride(0), t.shape[1])
         self.descs.append(_lib.GemmDesc(A.data_ptr(), Bm.data_ptr(), C.data_ptr(), _p(bias).value, _p(mask).value,
                                         _p(rs).value, _p(colsum).value, M, N, K, ld(A), ld(Bm), ld(C),
@@ -220,7 +222,7 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                       f=st.MLP_factor.layers, agg=agg, tw=_typed_weights(agg), e0=e0, e1=e1,
                       dist=t.dists[j].reshape(-1, K), g_y=None if g_y is None else g_y.reshape(B * N, -1).contiguous(),
                       g_d=None if g_d is None else g_d.reshape(-1, K).contiguous(),
-                      pool=_Pool(npar + 2 * B * N * D + B * E * (K + D) + 4096, x.device)))
+                      pool=_Pool(npar + 2 * B * N * D + B * E * (K + 2 * D) + 4096, x.device)))
     dev = S[0]["x"].device
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     gb = GemmBatch()
@@ -309,7 +311,8 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                     check(load().gn_typed_bwd_f32(_p(c["T"]), _p(c["Hc"]), _p(c["ef"]), _p(c["dfeat"]), _p(c["tw"]["b2mat"]),
                                                   _p(c["def"]), c["R"], c["K"], _HID, stream_handle()), "gn_typed_bwd_f32")
             # (pair rows: the self-loop's eo = 2 ori, and the pair-form scatter below weighs every row once)
-            stage(lambda c: c.update(deo=gb.add(c["T"], c["tw"]["W1cat"], new(c["R"], D),
+            # (K = K_types*128 is long and the output has few tiles: split K over workgroups, atomic accumulate)
+            stage(lambda c: c.update(deo=gb.add(c["T"], c["tw"]["W1cat"], c["pool"].take(c["R"], D), accum=True,
                                                 rs=_pair_row_weights(c["B"], c["N"], dev) if c["sym"] else None)))
             # eo = H ori  ->  d ori += H^T d eo  (the scatter kernel with divisor 1; its ori half is unused)
             scs = ops.agg_scatter_grouped([(c["deo"].view(c["B"], c["E"], D), c["H"], c["x"], c["sym"]) for c in S], 1.0)
@@ -329,8 +332,9 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                     grads[l0.weight], grads[l0.bias] = gW1[k * _HID:(k + 1) * _HID], c["gb1"][k * _HID:(k + 1) * _HID]
                     grads[l1.bias] = gb2[k]
                     # dW2_k = sum_r ef[r,k] dfeat[r] (x) h_k[r]
-                    grads[l1.weight] = gb.add(c["dfeat"], c["Hc"][:, k * _HID:(k + 1) * _HID], pool.take(D, _HID), tA=True,
-                                              accum=True, rs=c["ef"][:, k])
+                    # (as (ef_k h_k)^T dfeat written transposed: 128-row tiles instead of half-empty 64-row ones)
+                    grads[l1.weight] = gb.add(c["Hc"][:, k * _HID:(k + 1) * _HID], c["dfeat"], pool.take(D, _HID), tA=True,
+                                              accum=True, rs=c["ef"][:, k], tC=True)
             stage(e2n_weight_grads)
             S = S_all
 

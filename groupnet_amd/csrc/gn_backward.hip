@@ -49,11 +49,13 @@ struct GemmTable {
 // on the previous chunk; out-of-range elements are zeroed afterwards.
 constexpr int kALoads = BM * BK / kB, kBLoads = BN * BK / kB;
 
+// Issue-only: nothing here consumes a loaded value, so the waits land where the values are used — at the
+// LDS stores of the NEXT iteration, after the matrix-core phase.
 template <bool TRANS>   // TRANS: stored (K x M), m contiguous; else stored (M x K), k contiguous
-__device__ __forceinline__ void fetch_a(float (&va)[kALoads], const float* __restrict__ A, const float* __restrict__ rs,
-                                        int lda, int rs_ld, int M, int m0, int k0, int k_hi, int tid) {
+__device__ __forceinline__ unsigned fetch_a(float (&va)[kALoads], float (&vs)[kALoads], const float* __restrict__ A,
+                                            const float* __restrict__ rs, int lda, int rs_ld, int M, int m0, int k0,
+                                            int k_hi, int tid) {
   unsigned ok = 0;
-  size_t srow[kALoads];
 #pragma unroll
   for (int it = 0; it < kALoads; ++it) {
     const int idx = tid + it * kB;
@@ -61,36 +63,64 @@ __device__ __forceinline__ void fetch_a(float (&va)[kALoads], const float* __res
     const int m = m0 + mm, k = k0 + kk;
     if (m < M && k < k_hi) ok |= 1u << it;
     const int mc = min(m, M - 1), kc = min(k, k_hi - 1);
-    srow[it] = TRANS ? kc : mc;
-    va[it] = A[srow[it] * lda + (TRANS ? mc : kc)];
+    const size_t srow = TRANS ? kc : mc;
+    va[it] = A[srow * lda + (TRANS ? mc : kc)];
+    if (rs) vs[it] = rs[srow * rs_ld];
   }
-  if (rs) {
-    float vs[kALoads];
-#pragma unroll
-    for (int it = 0; it < kALoads; ++it) vs[it] = rs[srow[it] * rs_ld];
-#pragma unroll
-    for (int it = 0; it < kALoads; ++it) va[it] *= vs[it];
-  }
-#pragma unroll
-  for (int it = 0; it < kALoads; ++it)
-    if (!(ok >> it & 1u)) va[it] = 0.f;
+  return ok;
 }
 
 template <bool TRANS>   // TRANS: stored (N x K), k contiguous; else stored (K x N), n contiguous
-__device__ __forceinline__ void fetch_b(float (&vb)[kBLoads], const float* __restrict__ Bm, int ldb, int N, int n0,
-                                        int k0, int k_hi, int tid) {
+__device__ __forceinline__ unsigned fetch_b(float (&vb)[kBLoads], const float* __restrict__ Bm, int ldb, int N, int n0,
+                                            int k0, int k_hi, int tid) {
+  unsigned ok = 0;
 #pragma unroll
   for (int it = 0; it < kBLoads; ++it) {
     const int idx = tid + it * kB;
     const int nn = TRANS ? idx / BK : idx % BN, kk = TRANS ? idx % BK : idx / BN;
     const int n = n0 + nn, k = k0 + kk;
+    if (n < N && k < k_hi) ok |= 1u << it;
     const int nc = min(n, N - 1), kc = min(k, k_hi - 1);
-    const float v = TRANS ? Bm[(size_t)nc * ldb + kc] : Bm[(size_t)kc * ldb + nc];
-    vb[it] = (n < N && k < k_hi) ? v : 0.f;
+    vb[it] = TRANS ? Bm[(size_t)nc * ldb + kc] : Bm[(size_t)kc * ldb + nc];
+  }
+  return ok;
+}
+
+// Vector form of the same staging for interior tiles of 16-byte-aligned operands: one dwordx4 per 4 elements,
+// no clamps, no masks (4 + 2 loads per thread and chunk instead of 16 + 8).
+constexpr int kA4 = kALoads / 4, kB4 = kBLoads / 4;
+
+template <bool TRANS>
+__device__ __forceinline__ void fetch_a4(f32x4 (&va)[kA4], float (&vs)[kA4], const float* __restrict__ A,
+                                         const float* __restrict__ rs, int lda, int rs_ld, int M, int m0, int k0,
+                                         int tid) {
+#pragma unroll
+  for (int it = 0; it < kA4; ++it) {
+    const int idx = tid + it * kB;
+    // TRANS: 4 consecutive m of one k; else 4 consecutive k of one m.  Rows past M are clamped, not zeroed:
+    // they only feed output rows that are never stored.
+    const int mm = TRANS ? (idx % (BM / 4)) * 4 : idx / (BK / 4), kk = TRANS ? idx / (BM / 4) : (idx % (BK / 4)) * 4;
+    const int m = TRANS ? min(m0 + mm, M - 4) : min(m0 + mm, M - 1);
+    const size_t srow = TRANS ? (size_t)(k0 + kk) : (size_t)m;
+    va[it] = *reinterpret_cast<const f32x4*>(A + srow * lda + (TRANS ? m : k0 + kk));
+    if (rs) vs[it] = rs[srow * rs_ld];
   }
 }
 
-template <bool TA, bool TB>
+template <bool TRANS>
+__device__ __forceinline__ void fetch_b4(f32x4 (&vb)[kB4], const float* __restrict__ Bm, int ldb, int N, int n0,
+                                         int k0, int tid) {
+#pragma unroll
+  for (int it = 0; it < kB4; ++it) {
+    const int idx = tid + it * kB;
+    // TRANS (stored N x K): 4 consecutive k of one n; else 4 consecutive n of one k (columns past N clamped)
+    const int nn = TRANS ? idx / (BK / 4) : (idx % (BN / 4)) * 4, kk = TRANS ? (idx % (BK / 4)) * 4 : idx / (BN / 4);
+    const int n = TRANS ? min(n0 + nn, N - 1) : min(n0 + nn, N - 4);
+    vb[it] = *reinterpret_cast<const f32x4*>(TRANS ? Bm + (size_t)n * ldb + k0 + kk : Bm + (size_t)(k0 + kk) * ldb + n);
+  }
+}
+
+template <bool TA, bool TB, bool FAST>
 __device__ __forceinline__ void gemm_body(const GemmDesc& D, float (&As)[BK][BM + 4], float (&Bs)[BK][BN + 4]) {
   const int local = (int)blockIdx.x - D.tile0;
   const int split = local / D.gmn, t = local - split * D.gmn;
@@ -107,44 +137,111 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& D, float (&As)[BK][BM 
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
   const bool want_cs = TA && D.colsum != nullptr && tn == 0;
+  const bool transC = D.flags & GN_GEMM_TRANS_C;
   float cs = 0.f;
-  float va[kALoads], vb[kBLoads];
-  fetch_a<TA>(va, A, rs, lda, rs_ld, M, m0, k_lo, k_hi, tid);
-  fetch_b<TB>(vb, Bm, ldb, N, n0, k_lo, k_hi, tid);
+  float va[FAST ? 1 : kALoads], vs[FAST ? 1 : kALoads], vb[FAST ? 1 : kBLoads];
+  f32x4 va4[FAST ? kA4 : 1], vb4[FAST ? kB4 : 1];
+  float vs4[FAST ? kA4 : 1];
+  unsigned okA = 0, okB = 0;
+  if constexpr (FAST) {
+    fetch_a4<TA>(va4, vs4, A, rs, lda, rs_ld, M, m0, k_lo, tid);
+    fetch_b4<TB>(vb4, Bm, ldb, N, n0, k_lo, tid);
+  } else {
+    okA = fetch_a<TA>(va, vs, A, rs, lda, rs_ld, M, m0, k_lo, k_hi, tid);
+    okB = fetch_b<TB>(vb, Bm, ldb, N, n0, k_lo, k_hi, tid);
+  }
   for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
+    if constexpr (FAST) {
 #pragma unroll
-    for (int it = 0; it < kALoads; ++it) {
-      const int idx = tid + it * kB;
-      if (TA) As[idx / BM][idx % BM] = va[it];
-      else As[idx % BK][idx / BK] = va[it];
-    }
+      for (int it = 0; it < kA4; ++it) {
+        const int idx = tid + it * kB;
+        f32x4 v = va4[it];
+        if (rs) v *= vs4[it];
+        if (TA) {
+          *reinterpret_cast<f32x4*>(&As[idx / (BM / 4)][(idx % (BM / 4)) * 4]) = v;
+        } else {
+          const int mm = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
 #pragma unroll
-    for (int it = 0; it < kBLoads; ++it) {
-      const int idx = tid + it * kB;
-      if (TB) Bs[idx % BK][idx / BK] = vb[it];
-      else Bs[idx / BN][idx % BN] = vb[it];
+          for (int j = 0; j < 4; ++j) As[kk + j][mm] = v[j];
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < kB4; ++it) {
+        const int idx = tid + it * kB;
+        if (TB) {
+          const int nn = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Bs[kk + j][nn] = vb4[it][j];
+        } else {
+          *reinterpret_cast<f32x4*>(&Bs[idx / (BN / 4)][(idx % (BN / 4)) * 4]) = vb4[it];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < kALoads; ++it) {
+        const int idx = tid + it * kB;
+        float v = rs ? va[it] * vs[it] : va[it];
+        v = (okA >> it & 1u) ? v : 0.f;
+        if (TA) As[idx / BM][idx % BM] = v;
+        else As[idx % BK][idx / BK] = v;
+      }
+#pragma unroll
+      for (int it = 0; it < kBLoads; ++it) {
+        const int idx = tid + it * kB;
+        const float v = (okB >> it & 1u) ? vb[it] : 0.f;
+        if (TB) Bs[idx % BK][idx / BK] = v;
+        else Bs[idx / BN][idx % BN] = v;
+      }
     }
     __syncthreads();
     if (k0 + BK < k_hi) {   // the next chunk is in flight while the matrix cores run
-      fetch_a<TA>(va, A, rs, lda, rs_ld, M, m0, k0 + BK, k_hi, tid);
-      fetch_b<TB>(vb, Bm, ldb, N, n0, k0 + BK, k_hi, tid);
+      if constexpr (FAST) {
+        fetch_a4<TA>(va4, vs4, A, rs, lda, rs_ld, M, m0, k0 + BK, tid);
+        fetch_b4<TB>(vb4, Bm, ldb, N, n0, k0 + BK, tid);
+      } else {
+        okA = fetch_a<TA>(va, vs, A, rs, lda, rs_ld, M, m0, k0 + BK, k_hi, tid);
+        okB = fetch_b<TB>(vb, Bm, ldb, N, n0, k0 + BK, k_hi, tid);
+      }
     }
     if (want_cs && tid < BM) {
 #pragma unroll
       for (int kk = 0; kk < BK; ++kk) cs += As[kk][tid];
     }
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a = As[kk + hi][wave * 32 + l31];
-      const float b0 = Bs[kk + hi][l31], b1 = Bs[kk + hi][32 + l31];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    if (!transC) {
+#pragma unroll 4
+      for (int kk = 0; kk < BK; kk += 2) {
+        const float a = As[kk + hi][wave * 32 + l31];
+        const float b0 = Bs[kk + hi][l31], b1 = Bs[kk + hi][32 + l31];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+      }
+    } else {   // operands swapped: the accumulators hold the transposed tile (lanes run along m)
+#pragma unroll 4
+      for (int kk = 0; kk < BK; kk += 2) {
+        const float a = As[kk + hi][wave * 32 + l31];
+        const float b0 = Bs[kk + hi][l31], b1 = Bs[kk + hi][32 + l31];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a, acc1, 0, 0, 0);
+      }
     }
     __syncthreads();
   }
   if (want_cs && tid < BM && m0 + tid < M) atomicAdd(D.colsum + m0 + tid, cs);
   const bool accum = D.flags & GN_GEMM_ACCUM, relu = D.flags & GN_GEMM_RELU;
   const float alpha = D.alpha, beta = D.beta;
+  if (transC) {   // accumulate mode only: C is (N x M, ldc); lane = m, register = n
+    const int m = m0 + wave * 32 + l31;
+    if (m < M) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (n < N) atomicAdd(D.C + (size_t)n * D.ldc + m, alpha * (half ? acc1[r] : acc0[r]));
+        }
+    }
+    return;
+  }
   const float* __restrict__ bias = D.bias;
   const float* __restrict__ mask = D.mask;
 #pragma unroll
@@ -173,20 +270,33 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& D, float (&As)[BK][BM 
 
 // C = beta*C + alpha*op(A)op(B) (+bias)(relu)(mask), or with GN_GEMM_ACCUM: C += alpha*op(A)op(B) by atomics
 // (K split over workgroups).  fp32 matrix cores (v_mfma_f32_32x32x2_f32), operands staged through LDS
-// k-major so that either storage order of A and B loads coalesced.
-__global__ __launch_bounds__(kB) void gemm_mfma_kernel(const GemmTable T) {
-  __shared__ float As[BK][BM + 4];
-  __shared__ float Bs[BK][BN + 4];
+// k-major so that either storage order of A and B loads coalesced.  Two kernels so that each keeps its own
+// register budget: the vector-staging one (16-byte aligned operands, K a multiple of 32 — every large
+// problem of the backward) runs 4 workgroups per CU; the scalar one takes anything.
+template <bool FAST>
+__device__ __forceinline__ void gemm_dispatch(const GemmTable& T, float (&As)[BK][BM + 4], float (&Bs)[BK][BN + 4]) {
   int g = 0;
   for (int i = 1; i < T.n; ++i)
     if ((int)blockIdx.x >= T.d[i].tile0) g = i;
   g = gn_uniform(g);
   const GemmDesc& D = T.d[g];
   const int tt = gn_uniform(D.flags & (GN_GEMM_TRANS_A | GN_GEMM_TRANS_B));
-  if (tt == 0) gemm_body<false, false>(D, As, Bs);
-  else if (tt == GN_GEMM_TRANS_A) gemm_body<true, false>(D, As, Bs);
-  else if (tt == GN_GEMM_TRANS_B) gemm_body<false, true>(D, As, Bs);
-  else gemm_body<true, true>(D, As, Bs);
+  if (tt == 0) gemm_body<false, false, FAST>(D, As, Bs);
+  else if (tt == GN_GEMM_TRANS_A) gemm_body<true, false, FAST>(D, As, Bs);
+  else if (tt == GN_GEMM_TRANS_B) gemm_body<false, true, FAST>(D, As, Bs);
+  else gemm_body<true, true, FAST>(D, As, Bs);
+}
+
+__global__ __launch_bounds__(kB, 4) void gemm_mfma_kernel(const GemmTable T) {
+  __shared__ float As[BK][BM + 4];
+  __shared__ float Bs[BK][BN + 4];
+  gemm_dispatch<true>(T, As, Bs);
+}
+
+__global__ __launch_bounds__(kB) void gemm_mfma_edge_kernel(const GemmTable T) {
+  __shared__ float As[BK][BM + 4];
+  __shared__ float Bs[BK][BN + 4];
+  gemm_dispatch<false>(T, As, Bs);
 }
 
 __global__ __launch_bounds__(kB) void scale_kernel(float* __restrict__ C, long long total, int N, int ldc, float beta) {
@@ -593,7 +703,8 @@ inline int cap_grid(long long items, int per_block, int cap = 4096) {
 
 static int gemm_validate(const gn_gemm_desc_t& d) {
   if (d.A == nullptr || d.B == nullptr || d.C == nullptr) return GN_ERR_NULL;
-  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.ldc < d.N) return GN_ERR_SHAPE;
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.ldc < ((d.flags & GN_GEMM_TRANS_C) ? d.M : d.N)) return GN_ERR_SHAPE;
+  if ((d.flags & GN_GEMM_TRANS_C) && !(d.flags & GN_GEMM_ACCUM)) return GN_ERR_SHAPE;
   const bool tA = d.flags & GN_GEMM_TRANS_A, tB = d.flags & GN_GEMM_TRANS_B;
   if (d.lda < (tA ? d.M : d.K) || d.ldb < (tB ? d.K : d.N)) return GN_ERR_SHAPE;
   if (d.mask && d.ldmask < d.N) return GN_ERR_SHAPE;
@@ -610,31 +721,44 @@ extern "C" int gn_gemm_grouped_f32(const gn_gemm_desc_t* descs, int n, gn_stream
     if (rc != GN_OK) return rc;
   }
   hipStream_t s = (hipStream_t)stream;
-  for (int base = 0; base < n; base += kMaxDescs) {
-    GemmTable T;
-    T.n = n - base < kMaxDescs ? n - base : kMaxDescs;
-    long long tiles = 0;
-    for (int i = 0; i < T.n; ++i) {
-      const gn_gemm_desc_t& d = descs[base + i];
-      GemmDesc& g = T.d[i];
-      g.A = d.A; g.B = d.B; g.C = d.C; g.bias = d.bias; g.mask = d.mask; g.rs = d.rs; g.colsum = d.colsum;
-      g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc; g.ldmask = d.ldmask;
-      g.rs_ld = d.rs_ld; g.flags = d.flags; g.alpha = d.alpha; g.beta = d.beta;
-      const int gm = (d.M + BM - 1) / BM, gn = (d.N + BN - 1) / BN;
-      int splits = 1;
-      if (d.flags & GN_GEMM_ACCUM) {   // long K over few tiles: split K, partial sums by atomics
-        splits = (768 + gm * gn - 1) / (gm * gn);
-        const int max_splits = (d.K + 255) / 256;
-        splits = splits > max_splits ? max_splits : splits;
-      }
-      int kchunk = ((d.K + splits - 1) / splits + BK - 1) / BK * BK;
-      splits = (d.K + kchunk - 1) / kchunk;
-      g.tile0 = (int)tiles; g.gn = gn; g.gmn = gm * gn; g.kchunk = kchunk;
-      tiles += (long long)gm * gn * splits;
-      if (tiles > 0x7fffffffLL) return GN_ERR_SHAPE;
+  GemmTable T[2];            // [0] vector staging, [1] scalar staging; flushed when full
+  long long tiles[2] = {0, 0};
+  T[0].n = T[1].n = 0;
+  auto flush = [&](int which) {
+    if (T[which].n == 0) return;
+    if (which == 0) hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)tiles[0]), dim3(kB), 0, s, T[0]);
+    else hipLaunchKernelGGL(gemm_mfma_edge_kernel, dim3((unsigned)tiles[1]), dim3(kB), 0, s, T[1]);
+    T[which].n = 0;
+    tiles[which] = 0;
+  };
+  for (int i = 0; i < n; ++i) {
+    const gn_gemm_desc_t& d = descs[i];
+    const bool tA = d.flags & GN_GEMM_TRANS_A, tB = d.flags & GN_GEMM_TRANS_B;
+    const bool vec = ((uintptr_t)d.A & 15) == 0 && ((uintptr_t)d.B & 15) == 0 && d.lda % 4 == 0 && d.ldb % 4 == 0 &&
+                     d.K % BK == 0 && (!tA || (d.M % 4 == 0)) && (tB || (d.N % 4 == 0)) &&
+                     (!d.rs || true);
+    const int which = vec ? 0 : 1;
+    const int gm = (d.M + BM - 1) / BM, gn = (d.N + BN - 1) / BN;
+    int splits = 1;
+    if (d.flags & GN_GEMM_ACCUM) {   // long K over few tiles: split K, partial sums by atomics
+      splits = (512 + gm * gn - 1) / (gm * gn);
+      const int max_splits = (d.K + 511) / 512;
+      splits = splits > max_splits ? max_splits : splits;
     }
-    hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)tiles), dim3(kB), 0, s, T);
+    int kchunk = ((d.K + splits - 1) / splits + BK - 1) / BK * BK;
+    splits = (d.K + kchunk - 1) / kchunk;
+    const long long mine = (long long)gm * gn * splits;
+    if (mine > 0x7fffffffLL) return GN_ERR_SHAPE;
+    if (T[which].n == kMaxDescs || tiles[which] + mine > 0x7fffffffLL) flush(which);
+    GemmDesc& g = T[which].d[T[which].n++];
+    g.A = d.A; g.B = d.B; g.C = d.C; g.bias = d.bias; g.mask = d.mask; g.rs = d.rs; g.colsum = d.colsum;
+    g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc; g.ldmask = d.ldmask;
+    g.rs_ld = d.rs_ld; g.flags = d.flags & 31; g.alpha = d.alpha; g.beta = d.beta;
+    g.tile0 = (int)tiles[which]; g.gn = gn; g.gmn = gm * gn; g.kchunk = kchunk;
+    tiles[which] += mine;
   }
+  flush(0);
+  flush(1);
   return gn_check_launch();
 }
 

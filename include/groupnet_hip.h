@@ -335,6 +335,7 @@ int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, 
 #define GN_GEMM_TRANS_B 2
 #define GN_GEMM_RELU 4
 #define GN_GEMM_ACCUM 8
+#define GN_GEMM_TRANS_C 16   /* with GN_GEMM_ACCUM: the product is added into C^T, i.e. C is (N x M, ldc) */
 typedef struct {
   const float* A;
   const float* B;
