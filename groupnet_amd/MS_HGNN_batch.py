@@ -302,10 +302,9 @@ def invalidate_weight_caches(module: nn.Module) -> None:
         d = m.__dict__
         if "_pk_key" in d:
             m._pk_key = None
-        for name in ("_pk_n2e", "_pk_mlp"):
+        for name in ("_pk_n2e", "_pk_mlp", "_bwd_cat"):
             for hit in d.get(name, {}).values():
                 hit[3] = None
-        d.pop("_bwd_cat", None)
         if "_affine" in d:
             m._affine = None
 

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -63,7 +63,7 @@ class BlockExtras(ctypes.Structure):    # gn_block_extras_t
 
 class PackSeg(ctypes.Structure):       # gn_pack_seg_t
     _fields_ = [("src", _P), ("dst", _P), ("ld", _I), ("rows", _I), ("cols", _I), ("place_r", _I), ("place_c", _I),
-                ("IT", _I), ("scale", _F), ("_pad", _I)]
+                ("IT", _I), ("scale", _F), ("dst_ld", _I)]
 
 
 class GemmDesc(ctypes.Structure):      # gn_gemm_desc_t

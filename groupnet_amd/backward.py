@@ -22,6 +22,7 @@ the same two blocks repeated, walked backwards.
 from __future__ import annotations
 
 import ctypes
+import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -170,21 +171,52 @@ def _round_layers(mod, j: int):
             tail.layers)
 
 
-def _typed_weights(agg) -> dict:
-    """The K typed MLPs of one edge_aggregation as one wide layer (cached per parameter version)."""
+def _bwd_weights(mod, j: int) -> dict:
+    """The concatenated weight matrices round j's backward GEMMs read — the K typed MLPs as one wide layer,
+    MLP_distribution | MLP_factor side by side, the split attention layer 0 — assembled from the parameters
+    by ONE `PackPlan` launch per parameter version (no torch.cat, capturable)."""
     from .MS_HGNN_batch import _param_key
-    key = _param_key(agg.agg_mlp.parameters())
-    hit = agg.__dict__.get("_bwd_cat")
-    if hit is None or hit[0] != key:
-        with torch.no_grad():
-            l0 = [m.layers[0] for m in agg.agg_mlp]
-            l1 = [m.layers[1] for m in agg.agg_mlp]
-            cat = dict(W1cat=torch.cat([l.weight for l in l0], 0).contiguous(),       # (K*128, 64)
-                       b1cat=torch.cat([l.bias for l in l0], 0).contiguous(),         # (K*128)
-                       W2cat=torch.cat([l.weight for l in l1], 1).contiguous(),       # (64, K*128)
-                       b2mat=torch.stack([l.bias for l in l1], 0).contiguous())       # (K, 64)
-        agg.__dict__["_bwd_cat"] = (key, cat)
-        hit = agg.__dict__["_bwd_cat"]
+    (s0, s1), (a0, a1), st, agg, _ = _round_layers(mod, j)
+    d0, d1 = st.MLP_distribution.layers
+    f0, f1 = st.MLP_factor.layers
+    l0 = [m.layers[0] for m in agg.agg_mlp]
+    l1 = [m.layers[1] for m in agg.agg_mlp]
+    params = [a0.weight, a0.bias, d0.weight, d0.bias, d1.weight, d1.bias, f0.weight, f0.bias, f1.weight, f1.bias]
+    params += [p for l in l0 + l1 for p in (l.weight, l.bias)]
+    ptrs = tuple(p.data_ptr() for p in params)
+    cache = mod.__dict__.setdefault("_bwd_cat", {})
+    hit = cache.get(j)
+    if hit is None or hit[0] != ptrs:
+        K, D = mod.edge_types, ops.FEAT
+        plan = ops.PackPlan(params[0].device)
+        off = dict(W1cat=plan.alloc(K * _HID * D), b1cat=plan.alloc(K * _HID), W2cat=plan.alloc(D * K * _HID),
+                   b2mat=plan.alloc(K * D), Wd0=plan.alloc(256 * D), bd0=plan.alloc(256), Wd1=plan.alloc(_LGF_LD * 256),
+                   bd1=plan.alloc(_LGF_LD), Wpq=plan.alloc(D * D), bpq=plan.alloc(D))
+        for k in range(K):
+            plan.place(off["W1cat"], D, l0[k].weight, place_r=k * _HID)           # (K*128, 64)
+            plan.place(off["b1cat"], 0, l0[k].bias, place_c=k * _HID)
+            plan.place(off["W2cat"], K * _HID, l1[k].weight, place_c=k * _HID)     # (64, K*128)
+            plan.place(off["b2mat"], 0, l1[k].bias, place_c=k * D)                 # (K, 64)
+        plan.place(off["Wd0"], D, d0.weight)                                       # hidden layers side by side
+        plan.place(off["Wd0"], D, f0.weight, place_r=128)
+        plan.place(off["bd0"], 0, d0.bias)
+        plan.place(off["bd0"], 0, f0.bias, place_c=128)
+        plan.place(off["Wd1"], 256, d1.weight)                                     # rows 0..K-1: logits over hidden[:128]
+        plan.place(off["Wd1"], 256, f1.weight, place_r=K, place_c=128)             # row K: factor over hidden[128:]
+        plan.place(off["bd1"], 0, d1.bias)
+        plan.place(off["bd1"], 0, f1.bias, place_c=K)
+        plan.place(off["Wpq"], D, a0.weight[:, :D])                                # P = W[:, :64] x' + b
+        plan.place(off["Wpq"], D, a0.weight[:, D:], place_r=32)                    # Qn = W[:, 64:] x'
+        plan.place(off["bpq"], 0, a0.bias)
+        plan.finish()
+        shapes = dict(W1cat=(K * _HID, D), b1cat=(K * _HID,), W2cat=(D, K * _HID), b2mat=(K, D), Wd0=(256, D), bd0=(256,),
+                      Wd1=(_LGF_LD, 256), bd1=(_LGF_LD,), Wpq=(D, D), bpq=(D,))
+        cat = {n: plan.view(off[n], math.prod(shp)).view(*shp) for n, shp in shapes.items()}
+        hit = cache[j] = [ptrs, cat, plan, None]
+    key = _param_key(params)
+    if key != hit[3]:
+        hit[2].refresh()
+        hit[3] = key
     return hit[1]
 
 
@@ -219,7 +251,7 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
         npar = sum(p.numel() for m in (mod.node2edge_start_mlp[j], mod.attention_mlp[j], st, agg,
                                        nn.ModuleList([e0, e1])) for p in m.parameters())
         S.append(dict(mod=mod, x=x, x2=x.reshape(B * N, D), H=Hx, sym=sym, B=B, N=N, E=E, K=K, R=B * E, s0=s0, s1=s1, a0=a0, a1=a1, i=st.init_MLP.layers, d=st.MLP_distribution.layers,
-                      f=st.MLP_factor.layers, agg=agg, tw=_typed_weights(agg), e0=e0, e1=e1,
+                      f=st.MLP_factor.layers, agg=agg, tw=_bwd_weights(mod, j), e0=e0, e1=e1,
                       dist=t.dists[j].reshape(-1, K), g_y=None if g_y is None else g_y.reshape(B * N, -1).contiguous(),
                       g_d=None if g_d is None else g_d.reshape(-1, K).contiguous(),
                       pool=_Pool(npar + 2 * B * N * D + B * E * (K + 2 * D) + 4096, x.device)))
@@ -238,12 +270,8 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                                            relu=True)))
         stage(lambda c: c.update(xp=gb.add(c["x1"], W(c["s1"]), new(c["B"] * c["N"], D), tB=True, bias=b(c["s1"]))))
 
-        def pq_stage(c):
-            # attention layer 0 on cat(x'_n, e0_e), split by linearity: P = W[:, :64] x' + b, Qn = W[:, 64:] x'
-            c["pq"] = new(c["B"] * c["N"], D)
-            gb.add(c["xp"], W(c["a0"])[:, :D], c["pq"][:, :32], tB=True, bias=b(c["a0"]))
-            gb.add(c["xp"], W(c["a0"])[:, D:], c["pq"][:, 32:], tB=True)
-        stage(pq_stage)
+        # attention layer 0 on cat(x'_n, e0_e), split by linearity: P = W[:, :64] x' + b, Qn = W[:, 64:] x'
+        stage(lambda c: c.update(pq=gb.add(c["xp"], c["tw"]["Wpq"], new(c["B"] * c["N"], D), tB=True, bias=c["tw"]["bpq"])))
         for c in S:
             pk = c["mod"]._packed_n2e(j)      # (w2, b2) as the forward cached them: no host sync here
             c["w2"], c["b2"] = pk["w2"], pk["b2"]
@@ -255,18 +283,9 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                                            relu=True)))
         stage(lambda c: c.update(z=gb.add(c["z1"], W(c["i"][1]), new(c["R"], D), tB=True, bias=b(c["i"][1]))))
 
-        def dh1_stage(c):
-            c["dh1"] = new(c["R"], 256)        # hidden layers of MLP_distribution | MLP_factor
-            gb.add(c["z"], W(c["d"][0]), c["dh1"][:, :128], tB=True, bias=b(c["d"][0]), relu=True)
-            gb.add(c["z"], W(c["f"][0]), c["dh1"][:, 128:], tB=True, bias=b(c["f"][0]), relu=True)
-        stage(dh1_stage)
-
-        def lgf_stage(c):
-            K = c["K"]
-            c["lgf"] = new(c["R"], _LGF_LD)    # columns 0..K-1 logits, column K the factor pre-activation
-            gb.add(c["dh1"][:, :128], W(c["d"][1]), c["lgf"][:, :K], tB=True, bias=b(c["d"][1]))
-            gb.add(c["dh1"][:, 128:], W(c["f"][1]), c["lgf"][:, K:K + 1], tB=True, bias=b(c["f"][1]))
-        stage(lgf_stage)
+        # hidden layers of MLP_distribution | MLP_factor side by side, then (logits | factor pre-activation)
+        stage(lambda c: c.update(dh1=gb.add(c["z"], c["tw"]["Wd0"], new(c["R"], 256), tB=True, bias=c["tw"]["bd0"], relu=True)))
+        stage(lambda c: c.update(lgf=gb.add(c["dh1"], c["tw"]["Wd1"], new(c["R"], _LGF_LD), tB=True, bias=c["tw"]["bd1"])))
         for c in S:
             # ef per edge row; for pair rows ef_ij + ef_ji.  The forward's pair-form aggregation wants the
             # self-loop rows doubled (H = 2 folded into ef): ef_fwd, used only to re-compute feat.
@@ -346,17 +365,8 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                                                c["R"], c["K"], _LGF_LD, _TAU, c["N"] if c["sym"] else 0, stream_handle()),
                       "gn_gumbel_bwd_f32")
 
-        def dd1_stage(c):
-            K = c["K"]
-            c["dd1"] = new(c["R"], 256)
-            gb.add(c["dlgf"][:, :K], W(c["d"][1]), c["dd1"][:, :128], mask=c["dh1"][:, :128])
-            gb.add(c["dlgf"][:, K:K + 1], W(c["f"][1]), c["dd1"][:, 128:], mask=c["dh1"][:, 128:])
-        stage(dd1_stage)
-
-        def dz_stage(c):
-            c["dz"] = gb.add(c["dd1"][:, :128], W(c["d"][0]), new(c["R"], D))
-        stage(dz_stage)
-        stage(lambda c: gb.add(c["dd1"][:, 128:], W(c["f"][0]), c["dz"], beta=1.0))
+        stage(lambda c: c.update(dd1=gb.add(c["dlgf"], c["tw"]["Wd1"], new(c["R"], 256), mask=c["dh1"])))
+        stage(lambda c: c.update(dz=gb.add(c["dd1"], c["tw"]["Wd0"], new(c["R"], D))))
         stage(lambda c: c.update(dz1=gb.add(c["dz"], W(c["i"][1]), new(c["R"], 128), mask=c["z1"])))
         stage(lambda c: c.update(dedges=gb.add(c["dz1"], W(c["i"][0]), new(c["R"], D))))
         # ---------------- back through the attention-weighted pooling ----------------
@@ -370,8 +380,7 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                                                   _p(grads[c["a1"].bias]), c["B"], c["N"], c["E"], int(c["sym"]),
                                                   stream_handle()),
                       "gn_node2edge_bwd_f32")
-        stage(lambda c: gb.add(c["dpq"][:, :32], W(c["a0"])[:, :D], c["dxp"], beta=1.0))
-        stage(lambda c: gb.add(c["dpq"][:, 32:], W(c["a0"])[:, D:], c["dxp"], beta=1.0))
+        stage(lambda c: gb.add(c["dpq"], c["tw"]["Wpq"], c["dxp"], beta=1.0))
         stage(lambda c: c.update(dx1=gb.add(c["dxp"], W(c["s1"]), new(c["B"] * c["N"], 256), mask=c["x1"])))
 
         def dx_stage(c):
@@ -387,10 +396,15 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
             def wgrad(lin, dY, X):
                 grads[lin.weight] = gb.add(dY, X, pool.take(*lin.weight.shape), tA=True, accum=True,
                                            colsum=grads.setdefault(lin.bias, pool.take(*lin.bias.shape)))
-            wgrad(c["d"][1], c["dlgf"][:, :K], c["dh1"][:, :128])
-            wgrad(c["f"][1], c["dlgf"][:, K:K + 1], c["dh1"][:, 128:])
-            wgrad(c["d"][0], c["dd1"][:, :128], c["z"])
-            wgrad(c["f"][0], c["dd1"][:, 128:], c["z"])
+            # MLP_distribution | MLP_factor: gradients of the side-by-side matrices, handed out as views
+            gWd1, gbd1 = pool.take(_LGF_LD, 256), pool.take(_LGF_LD)
+            gb.add(c["dlgf"], c["dh1"], gWd1, tA=True, accum=True, colsum=gbd1)
+            grads[c["d"][1].weight], grads[c["f"][1].weight] = gWd1[:K, :128], gWd1[K:K + 1, 128:]
+            grads[c["d"][1].bias], grads[c["f"][1].bias] = gbd1[:K], gbd1[K:K + 1]
+            gWd0, gbd0 = pool.take(256, D), pool.take(256)
+            gb.add(c["dd1"], c["z"], gWd0, tA=True, accum=True, colsum=gbd0)
+            grads[c["d"][0].weight], grads[c["f"][0].weight] = gWd0[:128], gWd0[128:]
+            grads[c["d"][0].bias], grads[c["f"][0].bias] = gbd0[:128], gbd0[128:]
             wgrad(c["i"][1], c["dz"], c["z1"])
             wgrad(c["i"][0], c["dz1"], c["edges"])
             ga0 = pool.take(32, 2 * D)                               # the (32,128) layout of attention layer 0

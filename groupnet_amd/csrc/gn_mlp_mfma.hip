@@ -51,7 +51,8 @@ __global__ void pack_linear_kernel(const float* __restrict__ W, float* __restric
 }
 
 // Many weights, one launch.  A segment drops a source block (rows x cols, row-major, ld) into a packed
-// image at (place_r, place_c) of the image's virtual matrix — or, IT == 0, copies a vector — scaled.  The
+// image at (place_r, place_c) of the image's virtual matrix — or, IT == 0, into a plain row-major matrix
+// (dst_ld) / vector — scaled.  The
 // table lives in DEVICE memory: it is built once per module and parameter addresses, after which refreshing
 // every packed weight of the module after an optimizer step is one fill + this one launch (and capturable).
 __global__ __launch_bounds__(256) void pack_segments_kernel(const gn_pack_seg_t* __restrict__ segs) {
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void pack_segments_kernel(const gn_pack_seg_t*
     const float v = S.scale * S.src[(size_t)r * S.ld + c];
     const int row = S.place_r + r, col = S.place_c + c;
     if (S.IT == 0) {
-      S.dst[col] = v;
+      S.dst[(size_t)row * S.dst_ld + col] = v;
     } else {
       const int o = row >> 5, t = col >> 5, cc = col & 31;
       const int lane = (row & 31) + 32 * ((cc & 7) >> 2);

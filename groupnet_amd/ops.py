@@ -246,8 +246,8 @@ class PackPlan:
 
     Built once (per module and parameter addresses): `matrix` / `block` / `vector` record segments of
     `gn_pack_segments_f32` and hand out arena offsets; `finish()` uploads the segment table to the device.
-    `refresh()` = zero the arena + one kernel launch, reading the parameters in place — what has to happen
-    after every optimizer step, capturable in a hipGraph."""
+    `refresh()` = one kernel launch, reading the parameters in place — what has to happen after every
+    optimizer step, capturable in a hipGraph."""
 
     TILE = 1024
 
@@ -276,8 +276,19 @@ class PackPlan:
         cols = W.shape[1] - c0 if cols is None else cols
         self._keep.append(W)
         self._segs.append((W.data_ptr() + 4 * (r0 * W.stride(0) + c0), dst_off, W.stride(0), rows, cols, place_r, place_c,
-                           IT, scale))
+                           IT, scale, 0))
         self.max_elems = max(self.max_elems, rows * cols)
+
+    def place(self, dst_off: int, dst_ld: int, W: Tensor, place_r=0, place_c=0, scale=1.0) -> None:
+        """W (2-D, or a vector as one row) -> rows [place_r, ...) x columns [place_c, ...) of the plain row-major
+        (.., dst_ld) matrix at arena offset dst_off: concatenations without torch.cat."""
+        W = W.detach()
+        W = W.reshape(1, -1) if W.dim() == 1 else W
+        if W.dim() != 2 or W.stride(1) != 1 or W.dtype != torch.float32 or W.device != self.device:
+            raise ValueError("PackPlan.place: fp32 row-major matrix or vector on the plan's device")
+        self._keep.append(W)
+        self._segs.append((W.data_ptr(), dst_off, W.stride(0), W.shape[0], W.shape[1], place_r, place_c, 0, scale, dst_ld))
+        self.max_elems = max(self.max_elems, W.numel())
 
     def matrix(self, W: Tensor) -> int:
         """The whole (out x in) weight as a standard packed image; returns its arena offset."""
@@ -291,15 +302,15 @@ class PackPlan:
         if v.stride(1) != 1 or v.dtype != torch.float32 or v.device != self.device:
             raise ValueError("PackPlan.vector: contiguous fp32 vector on the plan's device")
         self._keep.append(v)
-        self._segs.append((v.data_ptr(), dst_off, v.shape[1], 1, v.shape[1], 0, place, 0, scale))
+        self._segs.append((v.data_ptr(), dst_off, v.shape[1], 1, v.shape[1], 0, place, 0, scale, 0))
         self.max_elems = max(self.max_elems, v.shape[1])
 
     def finish(self) -> "PackPlan":
         self.arena = torch.zeros(max(self.size, 64), dtype=torch.float32, device=self.device)
         base = self.arena.data_ptr()
         arr = (_lib.PackSeg * len(self._segs))()
-        for i, (src, off, ld, rows, cols, pr, pc, IT, scale) in enumerate(self._segs):
-            arr[i] = _lib.PackSeg(src, base + 4 * off, ld, rows, cols, pr, pc, IT, float(scale), 0)
+        for i, (src, off, ld, rows, cols, pr, pc, IT, scale, dst_ld) in enumerate(self._segs):
+            arr[i] = _lib.PackSeg(src, base + 4 * off, ld, rows, cols, pr, pc, IT, float(scale), dst_ld)
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.table = raw.to(self.device)
         self.sources = tuple(t.data_ptr() for t in self._keep)
@@ -309,7 +320,7 @@ class PackPlan:
         return self.arena[off:off + numel]
 
     def refresh(self) -> None:
-        self.arena.zero_()
+        # (segments always write the same positions: the padding zeroed in finish() stays zero)
         with torch.cuda.device(self.device):
             check(load().gn_pack_segments_f32(_ptr(self.table), len(self._segs), self.max_elems, stream_handle()),
                   "gn_pack_segments_f32")

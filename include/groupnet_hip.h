@@ -113,8 +113,10 @@ int gn_pack_linear_f32(const float* W, float* Wp, int out_features, int in_featu
 
 /* Many weights in one launch: segment i drops the source block src (rows x cols, row-major, ld) scaled by
  * `scale` into the packed image starting at dst, at (place_r, place_c) of the image's virtual matrix whose
- * packed rows hold IT 32-column tiles (the layout of gn_pack_linear_f32); IT == 0 copies a vector instead:
- * dst[place_c + j] = scale * src[j].  Nothing outside the block is written: zero the destination first.
+ * packed rows hold IT 32-column tiles (the layout of gn_pack_linear_f32); IT == 0 writes a plain row-major
+ * destination instead: dst[(place_r + r) * dst_ld + place_c + c] = scale * src[r][c] (vectors: rows = 1;
+ * concatenated weights for the backward's GEMMs).  Nothing outside the block is written: zero the
+ * destination once.
  * `segs` is a DEVICE array (built once per module; the refresh after an optimizer step is then one fill +
  * one launch, capturable in a hipGraph); max_elems = the largest rows*cols of any segment. */
 typedef struct {
@@ -122,7 +124,7 @@ typedef struct {
   float* dst;
   int ld, rows, cols, place_r, place_c, IT;
   float scale;
-  int _pad;
+  int dst_ld;
 } gn_pack_seg_t;
 int gn_pack_segments_f32(const gn_pack_seg_t* segs, int n_segs, int max_elems, gn_stream_t stream);
 

@@ -28,7 +28,7 @@ def _check(grads_hip, grads_ref, names):
         a, b = grads_hip[name], grads_ref[name]
         assert a is not None and b is not None, name
         assert a.shape == b.shape, (name, a.shape, b.shape)
-        scale = float(b.abs().max()) + 1e-4     # (softmax-shift directions have exactly zero gradient)
+        scale = float(b.abs().max()) + 1e-3     # (softmax-shift directions have exactly zero gradient: absolute floor)
         err = float((a.cpu() - b).abs().max()) / scale
         worst = max(worst, err)
         assert err <= 2e-3, (name, err, scale)

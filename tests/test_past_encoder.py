@@ -175,5 +175,5 @@ def test_encoder_training_gradients(which):
     for k in used:
         a, b = hip[k].grad, state[k].grad
         assert a is not None, k
-        scale = float(b.abs().max()) + 1e-4
+        scale = float(b.abs().max()) + 1e-3      # (softmax-shift directions have exactly zero gradient: absolute floor)
         assert float((a.cpu() - b).abs().max()) / scale <= 2e-3, k
