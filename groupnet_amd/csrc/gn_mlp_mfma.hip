@@ -1063,8 +1063,22 @@ extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_str
     }
     T.g[g].a = G;
     T.g[g].wpr = wpr;
+  }
+  // Workgroups are dispatched in index order: give the low indices to the group whose waves run longest
+  // (types x layers per wave), so the long waves start first and the short ones fill the tail.
+  static const bool as_given = getenv("GN_AGG_ORDER_AS_GIVEN") != nullptr;
+  if (!as_given) {
+    auto cost = [](const AggGroup& a) { return (long long)a.a.K * (a.a.A != nullptr ? 1 : 2) * 4 / a.wpr; };
+    for (int i = 1; i < n_groups; ++i)        // insertion sort, stable, n <= GN_MAX_GROUPS
+      for (int j = i; j > 0 && cost(T.g[j]) > cost(T.g[j - 1]); --j) {
+        const AggGroup tmp = T.g[j];
+        T.g[j] = T.g[j - 1];
+        T.g[j - 1] = tmp;
+      }
+  }
+  for (int g = 0; g < n_groups; ++g) {
     T.first_wg[g] = wg;
-    wg += (blocks32 * wpr + 3) / 4;
+    wg += ((T.g[g].a.rows + 31) / 32 * T.g[g].wpr + 3) / 4;
   }
   T.first_wg[n_groups] = wg;
   hipLaunchKernelGGL(agg_mlp_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, T);
