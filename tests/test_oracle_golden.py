@@ -160,3 +160,54 @@ def test_listall_oracle_matches_reference_goldens(name):
             assert float(H.sum(-1).min()) == float(H.sum(-1).max()) == float(max(int(s), 1))
             assert bool((torch.diagonal(H, dim1=1, dim2=2) == 1).all())      # agent i is in its own group
             assert float(c[f"margin_s{int(s)}"].min()) > 1e-4
+
+
+def _grad_case(name):
+    import numpy as np
+    import os
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", f"grad_{name}.npz")) as z:
+        return {k: z[k].copy() for k in z.files}
+
+
+def _grad_stats(g):
+    g64 = g.double()
+    return float(g64.sum()), float(g64.abs().sum()), float(g64.abs().max())
+
+
+@pytest.mark.parametrize("name", ["n11_b5", "n7_b3_nmp2"])
+def test_oracle_autograd_matches_reference_gradients(name):
+    """Pins the backward oracle: torch autograd through oracle.ms_hgnn_oracle reproduces the gradients the
+    REFERENCE's autograd produced (tests/golden/make_golden_backward.py) — dL/dh and selected parameter
+    gradients element-wise, every parameter gradient through its (sum, sum|.|, max|.|)."""
+    from conftest import load_state
+    c = _grad_case(name)
+    nmp = int(c["nmp"])
+    sfx = "_nmp2" if nmp == 2 else ""
+    h0, corr = torch.from_numpy(c["h"]), torch.from_numpy(c["corr"])
+    for prefix in ["pair"] + [f"hyper{int(s)}" for s in c["scales"]]:
+        state = {k: v.clone().requires_grad_(True) for k, v in load_state(("pairwise" if prefix == "pair" else "hyper") + sfx).items()}
+        U, i = [], 0
+        while f"{prefix}_U{i}" in c:
+            U.append(torch.from_numpy(c[f"{prefix}_U{i}"]))
+            i += 1
+        h = h0.clone().requires_grad_(True)
+        if prefix == "pair":
+            nf, fac = O.ms_hgnn_pairwise_forward(state, h, U, nmp_layers=nmp)
+        else:
+            nf, fac, H = O.ms_hgnn_hyper_forward(state, h, corr, int(prefix[5:]), U, nmp_layers=nmp)
+            assert torch.equal(H, torch.from_numpy(c[f"{prefix}_H"]))
+        assert float((nf.detach() - torch.from_numpy(c[f"{prefix}_node_feat"])).abs().max()) <= 1e-6
+        ((nf * torch.from_numpy(c[f"{prefix}_R1"])).sum() + (fac * torch.from_numpy(c[f"{prefix}_R2"])).sum()).backward()
+        gh = torch.from_numpy(c[f"{prefix}_g_h"])
+        assert float((h.grad - gh).abs().max()) <= 1e-5 * float(gh.abs().max())
+        for n, ref in zip(c[f"{prefix}_stat_names"], c[f"{prefix}_stats"]):
+            g = state[str(n)].grad
+            if np.isnan(ref[0]):
+                assert g is None, n
+                continue
+            got = _grad_stats(g)
+            assert abs(got[1] - ref[1]) <= 1e-4 * ref[1] + 1e-7 and abs(got[2] - ref[2]) <= 1e-4 * ref[2] + 1e-7, (n, got, ref)
+            assert abs(got[0] - ref[0]) <= 1e-4 * ref[1] + 1e-7, (n, got, ref)
+            if f"{prefix}_g/{n}" in c:
+                full = torch.from_numpy(c[f"{prefix}_g/{n}"])
+                assert float((g - full).abs().max()) <= 1e-5 * float(full.abs().max()) + 1e-8, n
