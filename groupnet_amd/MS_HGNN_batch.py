@@ -76,11 +76,20 @@ def _noise_iter(noise_u: Union[None, Tensor, Sequence[Tensor]]) -> Optional[Iter
     return iter(list(noise_u))
 
 
+def _plist(m: nn.Module) -> tuple:
+    """Parameters of `m` as a cached tuple (walking the module tree costs ~10 us per call and the engine asks
+    hundreds of times per step); dropped by `invalidate_weight_caches`."""
+    pl = m.__dict__.get("_gn_plist")
+    if pl is None:
+        pl = m.__dict__["_gn_plist"] = tuple(m.parameters())
+    return pl
+
+
 def _needs_grad(mod: nn.Module, *inputs: Optional[Tensor]) -> bool:
     """True when autograd is recording and the call involves anything that wants a gradient."""
     if not torch.is_grad_enabled():
         return False
-    return any(t is not None and t.requires_grad for t in inputs) or any(p.requires_grad for p in mod.parameters())
+    return any(t is not None and t.requires_grad for t in inputs) or any(p.requires_grad for p in _plist(mod))
 
 
 _warned_grad = False
@@ -162,7 +171,7 @@ class MLP_dict_softmax(nn.Module):
     def _packed(self) -> dict:
         """Weight stream of the edge-MLP kernel (layout: `ops.edge_stream`) and its biases, refreshed from the
         parameters by one `PackPlan` launch whenever they changed."""
-        params = list(self.parameters())
+        params = _plist(self)
         if self._plan is None or self._plan[0] != tuple(p.data_ptr() for p in params):
             K = self.bottleneck_dim
             i0, i1 = _two_layer(self.init_MLP)
@@ -242,7 +251,7 @@ class edge_aggregation(nn.Module):
         W (both layers, type by type), b1 / b2, and for the pairwise form layer 1 of all types as one
         (K*128 x 64) matrix applied per node (half the bias rides with each of the two nodes of a pair) and
         layer 2 re-ordered hidden-tile-major."""
-        params = list(self.agg_mlp.parameters())
+        params = _plist(self.agg_mlp)
         if self._plan is None or self._plan[0] != tuple(p.data_ptr() for p in params):
             K = self.edge_types
             l0 = [m.layers[0] for m in self.agg_mlp]
@@ -300,6 +309,7 @@ def invalidate_weight_caches(module: nn.Module) -> None:
     themselves — arenas and segment tables — stay; the next use re-runs their one refresh launch.)"""
     for m in module.modules():
         d = m.__dict__
+        d.pop("_gn_plist", None)
         if "_pk_key" in d:
             m._pk_key = None
         for name in ("_pk_n2e", "_pk_mlp", "_bwd_cat"):
@@ -344,7 +354,7 @@ class _MessagePassing(nn.Module):
     # -- packed weights ------------------------------------------------------------------------
     def _packed_n2e(self, idx: int) -> dict:
         start, att = self.node2edge_start_mlp[idx], self.attention_mlp[idx]
-        params = list(start.parameters()) + list(att.parameters())
+        params = _plist(start) + _plist(att)
         ptrs = tuple(p.data_ptr() for p in params)
         hit = self._pk_n2e.get(idx)
         if hit is None or hit[0] != ptrs:
@@ -375,7 +385,7 @@ class _MessagePassing(nn.Module):
         return hit[1]
 
     def _packed_mlp2(self, mlp: MLP) -> dict:
-        params = list(mlp.parameters())
+        params = _plist(mlp)
         ptrs = tuple(p.data_ptr() for p in params)
         hit = self._pk_mlp.get(id(mlp))
         if hit is None or hit[0] != ptrs:
@@ -416,7 +426,7 @@ class _MessagePassing(nn.Module):
         from .backward import MSHGNNFunction
         if out is not None:
             raise ValueError("out= is an inference-time extra; under autograd the module returns a new tensor")
-        return MSHGNNFunction.apply((self,), (H,), (noise_u,), h, *self.parameters())
+        return MSHGNNFunction.apply((self,), (H,), (noise_u,), h, *_plist(self))
 
 
 def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor], Hs: Sequence[Optional[Tensor]],

@@ -176,6 +176,12 @@ def _bwd_weights(mod, j: int) -> dict:
     MLP_distribution | MLP_factor side by side, the split attention layer 0 — assembled from the parameters
     by ONE `PackPlan` launch per parameter version (no torch.cat, capturable)."""
     from .MS_HGNN_batch import _param_key
+    cache = mod.__dict__.setdefault("_bwd_cat", {})
+    hit = cache.get(j)
+    if (hit is not None and hit[3] is not None and hit[3] == _param_key(hit[4])
+            and mod.attention_mlp[j].layers[0].weight is hit[4][0]
+            and mod.edge_aggregation_list[j].agg_mlp[-1].layers[1].bias is hit[4][-1]):
+        return hit[1]           # same parameter objects, addresses and versions as at the last refresh
     (s0, s1), (a0, a1), st, agg, _ = _round_layers(mod, j)
     d0, d1 = st.MLP_distribution.layers
     f0, f1 = st.MLP_factor.layers
@@ -184,8 +190,6 @@ def _bwd_weights(mod, j: int) -> dict:
     params = [a0.weight, a0.bias, d0.weight, d0.bias, d1.weight, d1.bias, f0.weight, f0.bias, f1.weight, f1.bias]
     params += [p for l in l0 + l1 for p in (l.weight, l.bias)]
     ptrs = tuple(p.data_ptr() for p in params)
-    cache = mod.__dict__.setdefault("_bwd_cat", {})
-    hit = cache.get(j)
     if hit is None or hit[0] != ptrs:
         K, D = mod.edge_types, ops.FEAT
         plan = ops.PackPlan(params[0].device)
@@ -212,7 +216,8 @@ def _bwd_weights(mod, j: int) -> dict:
         shapes = dict(W1cat=(K * _HID, D), b1cat=(K * _HID,), W2cat=(D, K * _HID), b2mat=(K, D), Wd0=(256, D), bd0=(256,),
                       Wd1=(_LGF_LD, 256), bd1=(_LGF_LD,), Wpq=(D, D), bpq=(D,))
         cat = {n: plan.view(off[n], math.prod(shp)).view(*shp) for n, shp in shapes.items()}
-        hit = cache[j] = [ptrs, cat, plan, None]
+        hit = cache[j] = [ptrs, cat, plan, None, params]
+    hit[4] = params
     key = _param_key(params)
     if key != hit[3]:
         hit[2].refresh()
@@ -248,8 +253,10 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
         E = ops.pair_count(N) if sym else Hx.shape[1]
         K = mod.edge_types
         (s0, s1), (a0, a1), st, agg, (e0, e1) = _round_layers(mod, j)
-        npar = sum(p.numel() for m in (mod.node2edge_start_mlp[j], mod.attention_mlp[j], st, agg,
-                                       nn.ModuleList([e0, e1])) for p in m.parameters())
+        npar = t.__dict__.setdefault("_npar", {}).get(j)
+        if npar is None:
+            npar = t._npar[j] = sum(p.numel() for m in (mod.node2edge_start_mlp[j], mod.attention_mlp[j], st, agg,
+                                                        nn.ModuleList([e0, e1])) for p in m.parameters())
         S.append(dict(mod=mod, x=x, x2=x.reshape(B * N, D), H=Hx, sym=sym, B=B, N=N, E=E, K=K, R=B * E, s0=s0, s1=s1, a0=a0, a1=a1, i=st.init_MLP.layers, d=st.MLP_distribution.layers,
                       f=st.MLP_factor.layers, agg=agg, tw=_bwd_weights(mod, j), e0=e0, e1=e1,
                       dist=t.dists[j].reshape(-1, K), g_y=None if g_y is None else g_y.reshape(B * N, -1).contiguous(),

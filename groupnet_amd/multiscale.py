@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .MS_HGNN_batch import MS_HGNN_hyper, MS_HGNN_oridinary, _needs_grad, run_message_passing
+from .MS_HGNN_batch import MS_HGNN_hyper, MS_HGNN_oridinary, _needs_grad, _plist, run_message_passing
 
 Tensor = torch.Tensor
 
@@ -43,7 +43,7 @@ def multiscale_autograd(pair: MS_HGNN_oridinary, hypers: Sequence[MS_HGNN_hyper]
     nz = tuple(noise_u) if noise_u is not None else (None,) * (1 + S)
     if len(nz) != 1 + S:
         raise ValueError(f"noise_u: need {1 + S} entries (pairwise + one per scale)")
-    params = [p for m in mods for p in m.parameters()]
+    params = [p for m in mods for p in _plist(m)]
     res = MSHGNNFunction.apply(mods, (None, *Hs), nz, *([f] * (1 + S)), *params)
     return torch.cat([f, *res[0::2]], dim=-1), new_H
 
