@@ -9,7 +9,6 @@
 //                          for input gradients dX = dY W and for weight gradients dW = dY^T X (K = rows,
 //                          split over workgroups, bias gradient as a side output);
 //   gn_typed_bwd_f32       the per-type scalings / dot products of the typed aggregation;
-//   gn_colsum_f32          bias gradients db = sum_rows dY;
 //   gn_typed_scale/dot     the per-row, per-type scalings of the typed aggregation;
 //   gn_gumbel_bwd_f32      back through fac * softmax((logits + g) / tau) and the sigmoid;
 //   gn_node2edge_bwd_f32   back through the attention-weighted pooling (one wave per hyperedge, like the
@@ -305,42 +304,6 @@ __global__ __launch_bounds__(kB) void scale_kernel(float* __restrict__ C, long l
     const int n = (int)(idx - m * N);
     float* c = C + (size_t)m * ldc + n;
     *c = beta == 0.f ? 0.f : beta * *c;
-  }
-}
-
-// out[c] (+)= sum_r X[r][c]
-__global__ __launch_bounds__(kB) void colsum_kernel(const float* __restrict__ X, float* __restrict__ out, int rows,
-                                                    int cols, int ld, int rows_per_block) {
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  for (int c = threadIdx.x; c < cols; c += kB) {
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += X[(size_t)r * ld + c];
-    atomicAdd(out + c, s);
-  }
-}
-
-// dst[r][c] = s[r*lds + off] * src[r][c]
-__global__ __launch_bounds__(kB) void rowscale_kernel(float* __restrict__ dst, const float* __restrict__ src,
-                                                      const float* __restrict__ s, long long rows, int cols, int lds,
-                                                      int off) {
-  const long long total = rows * cols;
-  for (long long idx = (long long)blockIdx.x * kB + threadIdx.x; idx < total; idx += (long long)gridDim.x * kB) {
-    const long long r = idx / cols;
-    dst[idx] = s[r * lds + off] * src[idx];
-  }
-}
-
-// out[r*ldo + off] = <a[r], b[r]>  (cols <= 64: one wave per row)
-__global__ __launch_bounds__(kB) void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                    float* __restrict__ out, long long rows, int cols, int ldo,
-                                                    int off) {
-  const int lane = threadIdx.x & 63;
-  for (long long r = (long long)blockIdx.x * (kB / 64) + (threadIdx.x >> 6); r < rows;
-       r += (long long)gridDim.x * (kB / 64)) {
-    float v = 0.f;
-    for (int c = lane; c < cols; c += 64) v += a[r * cols + c] * b[r * cols + c];
-    v = gn_wave_sum(v);
-    if (lane == 0) out[r * ldo + off] = v;
   }
 }
 
@@ -781,38 +744,6 @@ extern "C" int gn_gemm_f32(const float* A, const float* B, float* C, int M, int 
     d.beta = 0.f;
   }
   return gn_gemm_grouped_f32(&d, 1, stream);
-}
-
-extern "C" int gn_colsum_f32(const float* X, float* out, int rows, int cols, int ld, gn_stream_t stream) {
-  GN_REQUIRE_PTR(X);
-  GN_REQUIRE_PTR(out);
-  if (rows <= 0 || cols <= 0 || ld < cols) return GN_ERR_SHAPE;
-  const int rpb = rows < 4096 ? 64 : 256;
-  hipLaunchKernelGGL(colsum_kernel, dim3((rows + rpb - 1) / rpb), dim3(kB), 0, (hipStream_t)stream, X, out, rows, cols,
-                     ld, rpb);
-  return gn_check_launch();
-}
-
-extern "C" int gn_rowscale_f32(float* dst, const float* src, const float* s, long long rows, int cols, int lds, int off,
-                               gn_stream_t stream) {
-  GN_REQUIRE_PTR(dst);
-  GN_REQUIRE_PTR(src);
-  GN_REQUIRE_PTR(s);
-  if (rows <= 0 || cols <= 0) return GN_ERR_SHAPE;
-  hipLaunchKernelGGL(rowscale_kernel, dim3(cap_grid(rows * cols, kB)), dim3(kB), 0, (hipStream_t)stream, dst, src, s,
-                     rows, cols, lds, off);
-  return gn_check_launch();
-}
-
-extern "C" int gn_rowdot_f32(const float* a, const float* b, float* out, long long rows, int cols, int ldo, int off,
-                             gn_stream_t stream) {
-  GN_REQUIRE_PTR(a);
-  GN_REQUIRE_PTR(b);
-  GN_REQUIRE_PTR(out);
-  if (rows <= 0 || cols <= 0) return GN_ERR_SHAPE;
-  hipLaunchKernelGGL(rowdot_kernel, dim3(cap_grid(rows, kB / 64)), dim3(kB), 0, (hipStream_t)stream, a, b, out, rows,
-                     cols, ldo, off);
-  return gn_check_launch();
 }
 
 extern "C" int gn_gumbel_bwd_f32(const float* dist, const float* lgf, const float* def, const float* gdist, float* dlgf,

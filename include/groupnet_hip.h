@@ -313,8 +313,6 @@ int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, 
  *   op(A) = A (M x K, lda) or, transA, A^T with A stored (K x M, lda); op(B) = B (K x N, ldb) or, transB,
  *   B^T with B stored (N x K, ldb).  With few output tiles and K >= 4096 (weight gradients dW = dY^T X)
  *   K is split over workgroups and partial sums are added atomically (then no bias/relu/mask).
- * gn_colsum_f32: out[c] += sum_r X[r][c]   (bias gradients; out must hold the running sum / zeros).
- * gn_rowscale_f32: dst[r][:] = s[r*lds + off] * src[r][:];  gn_rowdot_f32: out[r*ldo + off] = <a[r], b[r]>.
  * gn_gumbel_bwd_f32: back through edge_feat = sigmoid(f) * dist, dist = softmax((logits + g)/tau)
  *   (model/MS_HGNN_batch.py:45-50): dist (rows,K), lgf (rows,ldl) whose column K is f, def = d edge_feat,
  *   gdist = d dist or NULL -> dlgf (rows,ldl): columns 0..K-1 = d logits, column K = d f, rest 0.
@@ -367,11 +365,6 @@ int gn_gumbel_ef_f32(const float* dist, const float* lgf, float* ef, long long r
  * def[r][k] = <T[r,k,:], Hc[r,k,:]> + <dfeat[r], b2[k]> and T[r,k,:] <- ef[r][k] * T[r,k,:] * (Hc > 0). */
 int gn_typed_bwd_f32(float* T, const float* Hc, const float* ef, const float* dfeat, const float* b2, float* def,
                      long long rows, int K, int hid, gn_stream_t stream);
-int gn_colsum_f32(const float* X, float* out, int rows, int cols, int ld, gn_stream_t stream);
-int gn_rowscale_f32(float* dst, const float* src, const float* s, long long rows, int cols, int lds, int off,
-                    gn_stream_t stream);
-int gn_rowdot_f32(const float* a, const float* b, float* out, long long rows, int cols, int ldo, int off,
-                  gn_stream_t stream);
 int gn_gumbel_bwd_f32(const float* dist, const float* lgf, const float* def, const float* gdist, float* dlgf,
                       long long rows, int K, int ldl, float tau, int sym_N, gn_stream_t stream);
 int gn_node2edge_bwd_f32(const float* xp, const float* pq, const float* H, const float* w2, const float* b2,
