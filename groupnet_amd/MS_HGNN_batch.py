@@ -12,7 +12,9 @@ There is no CPU path and no torch-math fallback; CPU tensors raise ``ValueError`
 
 Differences from the reference that a caller can observe
   * tensors must be on the GPU (the reference fork only runs on the CPU);
-  * forward-only: outputs carry no autograd graph (SURVEY.md §8f rank 2);
+  * under autograd the two MS_HGNN modules return outputs with a HIP backward attached
+    (``groupnet_amd.backward``); their sub-modules (``MLP``,
+    ``MLP_dict_softmax``, ``edge_aggregation``) called on their own are forward-only;
   * optional ``noise_u=`` lets the caller inject the uniforms of the Gumbel noise.
     By default they are drawn exactly as the reference does — ``torch.rand`` on the
     global CPU generator, one ``(B,E,K)`` draw per MLP_dict_softmax call
@@ -100,10 +102,11 @@ def _check_forward_only(*inputs: Tensor) -> None:
     if not torch.is_grad_enabled():
         return
     if any(t is not None and t.requires_grad for t in inputs):
-        raise RuntimeError("groupnet_amd MS-HGNN kernels are forward-only: an input requires grad. "
-                           "Call under torch.no_grad() (backward is not built yet).")
+        raise RuntimeError("this sub-module is forward-only when called on its own: an input requires grad. "
+                           "Differentiate through MS_HGNN_oridinary / MS_HGNN_hyper (groupnet_amd.backward) or call "
+                           "it under torch.no_grad().")
     if not _warned_grad:
-        warnings.warn("groupnet_amd MS-HGNN forward is forward-only; outputs carry no autograd graph.")
+        warnings.warn("groupnet_amd sub-modules called on their own are forward-only; outputs carry no autograd graph.")
         _warned_grad = True
 
 
