@@ -545,7 +545,12 @@ constexpr int kTypeSteps = 64;
 struct AggGroup {
   gn_agg_group_t a;
   int wpr;
+  int stage;   // pair form, wpr == 1: the workgroup stages the per-node pre-activations of its scenes in LDS
 };
+constexpr int kStagePitch = 128 + 4;                 // floats per staged node row (one type)
+constexpr int kStageFloats = 4 * 32 * 64;            // the LDS the kernel owns (shared with the wpr > 1 partial sums)
+constexpr int kStageMaxNodes = kStageFloats / kStagePitch;
+constexpr int kStageLoads = (kStageMaxNodes * 32 + 255) / 256;
 __device__ __forceinline__ void relu_scale16(f32x16& a, float w) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f) * w;
@@ -561,7 +566,8 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
   const int sub = wave % wpr;                       // which share of the types
   const int blk = wg * (4 / wpr) + wave / wpr;      // which row block
   const bool any_rows = blk * 32 < rows;
-  if (wpr == 1 && !any_rows) return;
+  const bool staged = T.g[gi].stage != 0;
+  if (wpr == 1 && !any_rows && !staged) return;   // (a staged workgroup keeps all its waves for the barriers)
   const RowBlock rb = row_block(rows, any_rows ? blk : 0);
   const int lane = rb.lane, h = rb.h;
   f32x16 out[2];
@@ -575,7 +581,93 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
   const float* b2 = G.b2;
 
   int k = sub;
-  if (G.A != nullptr) {
+  if (G.A != nullptr && staged) {
+    // ---- pair form, staged: every lane needs the pre-activations of ITS two nodes — 16-byte pieces scattered
+    // over up to 32 rows per load, which makes the texture-address path, not the matrix cores, the limiter.
+    // The 4 row blocks of this workgroup touch at most 3 scenes, i.e. a short run of consecutive node rows: the
+    // workgroup copies that run (one type at a time, coalesced, prefetched in registers under the previous
+    // type's MFMAs) into LDS, and the lanes pick their rows from there.
+    float* stage = &part[0][0][0];
+    const int N = G.N, P = G.E;
+    const int r0 = wg * 128, r1 = min(rows - 1, r0 + 127);
+    const int node0 = (r0 / P) * N;
+    const int nodes = (r1 / P + 1) * N - node0;
+    const size_t ldA = (size_t)K * 128;
+    const f32x4* Ag = reinterpret_cast<const f32x4*>(G.A + (size_t)node0 * ldA);
+    const int total4 = nodes * 32;                      // float4 pieces per type
+    f32x4 pre[kStageLoads];
+    auto fetch = [&](int kk) {
+#pragma unroll
+      for (int it = 0; it < kStageLoads; ++it) {
+        const int idx = min((int)threadIdx.x + it * 256, total4 - 1);
+        pre[it] = Ag[(size_t)(idx >> 5) * (ldA / 4) + kk * 32 + (idx & 31)];
+      }
+    };
+    auto commit = [&]() {
+#pragma unroll
+      for (int it = 0; it < kStageLoads; ++it) {
+        const int idx = (int)threadIdx.x + it * 256;
+        if (idx < total4) *reinterpret_cast<f32x4*>(stage + (idx >> 5) * kStagePitch + (idx & 31) * 4) = pre[it];
+      }
+    };
+    int i = 0, j = 0;
+    {
+      const int b = rb.row_ld / P, p = rb.row_ld - b * P;
+      gn_pair_decode(p, N, i, j);
+      i += b * N - node0;
+      j += b * N - node0;
+    }
+    const float* Si = stage + i * kStagePitch;
+    const float* Sj = stage + j * kStagePitch;
+    WRing ring;
+    ring_prime(ring, Wl);
+    fetch(0);
+    commit();
+    __syncthreads();
+    PreTile pa = load_pre(Si, h), pb = load_pre(Sj, h);
+    float efk = efrow[0];
+    float b2f0 = h == 0 ? b2[lane & 31] : 0.f;
+    float b2f1 = h == 0 ? b2[32 + (lane & 31)] : 0.f;
+#pragma unroll 1
+    for (k = 0; k < K; ++k) {
+      const int kc = k + 1 < K ? k + 1 : k;
+      fetch(kc);                                        // next type's rows: in flight during this type's MFMAs
+      const f32x4* base = Wl + (size_t)k * 32 * kStep;
+      const f32x4* base_next = Wl + (size_t)kc * 32 * kStep;
+      const float efk_next = efrow[kc];
+      const float b2n0 = h == 0 ? b2[kc * 64 + (lane & 31)] : 0.f;
+      const float b2n1 = h == 0 ? b2[kc * 64 + 32 + (lane & 31)] : 0.f;
+      const float efb = h == 0 ? efk : 0.f;
+      out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f0, efb, out[0], 0, 0, 0);
+      out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f1, efb, out[1], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x16 hid1[1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int cidx = 0; cidx < 4; ++cidx)
+            hid1[0][4 * q + cidx] = fmaxf(pa.v[q][cidx] + pb.v[q][cidx], 0.f) * efk;
+        if (t < 3) {
+          pa = load_pre(Si + 32 * (t + 1), h);
+          pb = load_pre(Sj + 32 * (t + 1), h);
+        }
+        const f32x4* cur = base + t * 8 * kStep;
+        const f32x4* nxt = t < 3 ? cur + 8 * kStep : base_next;
+        mma_tile<1, 0, NoSide, 4>(cur, cur + 4 * kStep, ring, hid1, out[0], NoSide(), nxt);
+        mma_tile<1, 4>(cur + 4 * kStep, nxt, ring, hid1, out[1]);
+      }
+      __syncthreads();                                  // every wave has read type k's rows
+      commit();
+      __syncthreads();
+      pa = load_pre(Si, h);
+      pb = load_pre(Sj, h);
+      efk = efk_next;
+      b2f0 = b2n0;
+      b2f1 = b2n1;
+    }
+    if (!any_rows) return;
+  } else if (G.A != nullptr) {
     // ---- pair form: the first layer was applied per node (A = W1 ori + b1/2 for every type) ----------
     // W = per type 4 hidden tiles x (2 output tiles x 4 steps), consumed strictly in order: 8 steps
     // (one ring turn) per hidden tile.
@@ -1063,6 +1155,9 @@ extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_str
     }
     T.g[g].a = G;
     T.g[g].wpr = wpr;
+    // pair form with one wave per row block: stage the scenes' node rows in LDS when they fit
+    static const bool no_stage = getenv("GN_AGG_NO_STAGE") != nullptr;
+    T.g[g].stage = (!no_stage && G.A != nullptr && wpr == 1 && (127 / G.E + 2) * G.N <= kStageMaxNodes) ? 1 : 0;
   }
   // Workgroups are dispatched in index order: give the low indices to the group whose waves run longest
   // (types x layers per wave), so the long waves start first and the short ones fill the tail.
