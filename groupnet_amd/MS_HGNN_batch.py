@@ -508,11 +508,13 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
         stages = [m.nmp_mlps[l] for m in mods]
         if l % 2 == 0:
             agg = edge2node(edge_feats, node_feats, idx)
-            node_feats = ops.mlp2_grouped([(a, m._packed_mlp2(st), None) for a, m, st in zip(agg, mods, stages)])
+            keep = [] if traces is not None else None
+            node_feats = ops.mlp2_grouped([(a, m._packed_mlp2(st), None) for a, m, st in zip(agg, mods, stages)], keep)
             idx += 1
             if traces is not None:
-                for t, x in zip(traces, node_feats):
+                for t, x, kd in zip(traces, node_feats, keep):
                     t.xs.append(x)
+                    t.tails.append(kd)
         else:
             res = edge_mlp(stages, node2edge(node_feats, idx), traces is not None)
             edge_feats = [r[0] for r in res]
@@ -523,10 +525,14 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
     ends = [(a, m._packed_mlp2(m.nmp_mlp_end), o) for a, m, o in zip(agg, mods, outs)]
     # the last MLP writes in place when `out` is given; grouped when every group has the same stride
     strides = {(-1 if o is None else o.stride(-2)) for o in outs}
+    keep = [] if traces is not None else None
     if len(strides) == 1:
-        node_feats = ops.mlp2_grouped(ends)
+        node_feats = ops.mlp2_grouped(ends, keep)
     else:
-        node_feats = [ops.mlp2(*e) for e in ends]
+        node_feats = [ops.mlp2_grouped([e], keep)[0] for e in ends]
+    if traces is not None:
+        for t, kd in zip(traces, keep):
+            t.tails.append(kd)
     return list(zip(node_feats, factors))
 
 

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -53,7 +53,7 @@ class ScatterGroup(ctypes.Structure):   # gn_scatter_group_t
 
 class Mlp2Group(ctypes.Structure):      # gn_mlp2_group_t
     _fields_ = [("x", _P), ("W", _P), ("bias", _P), ("y", _P), ("feat", _P), ("H", _P), ("ori", _P), ("E", _I),
-                ("sym", _I)]
+                ("sym", _I), ("in_out", _P), ("hid_out", _P)]
 
 
 class BlockExtras(ctypes.Structure):    # gn_block_extras_t

@@ -161,6 +161,7 @@ class ModuleTrace:
         self.mod, self.H = mod, H
         self.xs: List[Tensor] = [h]          # node features entering round j
         self.dists: List[Tensor] = []        # dist of round j (B,E,K)
+        self.tails: List[dict] = []          # round j's closing MLP: {"x": cat(H^T feat, ori)/N, "hid": relu(layer 0)}
 
 
 def _round_layers(mod, j: int):
@@ -259,7 +260,7 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                                                         nn.ModuleList([e0, e1])) for p in m.parameters())
         S.append(dict(mod=mod, x=x, x2=x.reshape(B * N, D), H=Hx, sym=sym, B=B, N=N, E=E, K=K, R=B * E, s0=s0, s1=s1, a0=a0, a1=a1, i=st.init_MLP.layers, d=st.MLP_distribution.layers,
                       f=st.MLP_factor.layers, agg=agg, tw=_bwd_weights(mod, j), e0=e0, e1=e1,
-                      dist=t.dists[j].reshape(-1, K), g_y=None if g_y is None else g_y.reshape(B * N, -1).contiguous(),
+                      tail=t.tails[j], dist=t.dists[j].reshape(-1, K), g_y=None if g_y is None else g_y.reshape(B * N, -1).contiguous(),
                       g_d=None if g_d is None else g_d.reshape(-1, K).contiguous(),
                       pool=_Pool(npar + 2 * B * N * D + B * E * (K + 2 * D) + 4096, x.device)))
     dev = S[0]["x"].device
@@ -294,14 +295,12 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
         stage(lambda c: c.update(dh1=gb.add(c["z"], c["tw"]["Wd0"], new(c["R"], 256), tB=True, bias=c["tw"]["bd0"], relu=True)))
         stage(lambda c: c.update(lgf=gb.add(c["dh1"], c["tw"]["Wd1"], new(c["R"], _LGF_LD), tB=True, bias=c["tw"]["bd1"])))
         for c in S:
-            # ef per edge row; for pair rows ef_ij + ef_ji.  The forward's pair-form aggregation wants the
-            # self-loop rows doubled (H = 2 folded into ef): ef_fwd, used only to re-compute feat.
+            # ef per edge row; for pair rows ef_ij + ef_ji (self-loop rows not doubled: the typed backward below
+            # works with dfeat = the pair gather of d(H^T feat), which carries the self-loop's 2)
             c["ef"] = new(c["R"], c["K"])
-            c["ef_fwd"] = new(c["R"], c["K"]) if c["sym"] else c["ef"]
             with torch.cuda.device(dev):
-                for dst, w in ((c["ef"], 1.0), (c["ef_fwd"], 2.0)) if c["sym"] else ((c["ef"], 1.0),):
-                    check(load().gn_gumbel_ef_f32(_p(c["dist"]), _p(c["lgf"]), _p(dst), c["R"], c["K"], _LGF_LD,
-                                                  c["N"] if c["sym"] else 0, w, stream_handle()), "gn_gumbel_ef_f32")
+                check(load().gn_gumbel_ef_f32(_p(c["dist"]), _p(c["lgf"]), _p(c["ef"]), c["R"], c["K"], _LGF_LD,
+                                              c["N"] if c["sym"] else 0, 1.0, stream_handle()), "gn_gumbel_ef_f32")
             c["def"] = c["pool"].take(c["R"], c["K"])
             c["dx"] = None
 
@@ -313,13 +312,10 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                 c["eo"], c["eo2"] = eo, eo.view(c["R"], D)
             stage(lambda c: c.update(Hc=gb.add(c["eo2"], c["tw"]["W1cat"], new(c["R"], c["K"] * _HID), tB=True,
                                                bias=c["tw"]["b1cat"], relu=True)))
-            feats = ops.agg_mlp_grouped([(c["eo"], c["ef_fwd"].view(c["B"], c["E"], c["K"]), c["agg"]._packed(), c["K"])
-                                         for c in S])
-            aggs = ops.agg_scatter_grouped([(f, c["H"], c["x"], c["sym"]) for f, c in zip(feats, S)])
-            for c, a in zip(S, aggs):
-                c["agg2"] = a.view(c["B"] * c["N"], 2 * D)      # cat(H^T feat, ori) / N
-            stage(lambda c: c.update(y1=gb.add(c["agg2"], W(c["e0"]), new(c["B"] * c["N"], 128), tB=True,
-                                               bias=b(c["e0"]), relu=True)))
+            # cat(H^T feat, ori) / N and the closing MLP's hidden layer were kept by the forward (the fused
+            # scatter+MLP kernel writes them on request), so feat is not re-computed
+            for c in S:
+                c["agg2"], c["y1"] = c["tail"]["x"], c["tail"]["hid"]
             # ---------------- back through MLP(edge2node) ----------------
             stage(lambda c: c.update(dy1=gb.add(c["g_y"], W(c["e1"]), new(c["B"] * c["N"], 128), mask=c["y1"])))
 

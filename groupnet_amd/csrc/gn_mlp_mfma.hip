@@ -880,7 +880,9 @@ __global__ __launch_bounds__(256) void mlp2_kernel(GroupTable<gn_mlp2_group_t> T
   chain_begin(c, G.W, G.bias, rb.lane);
   f32x16 in[IT], hid[HT];
   mlp2_rows<IT>(G, rb.row_ld, rb.h, N, divisor, in);
+  if (G.in_out != nullptr) store_rows<IT>(G.in_out, 32 * IT, rb.row, rb.h, rb.live, in);     // kept for the backward
   chain_linear<HT, IT, true>(c, in, hid);
+  if (G.hid_out != nullptr) store_rows<HT>(G.hid_out, 32 * HT, rb.row, rb.h, rb.live, hid);
   const int OT = (dout + 31) >> 5;
   constexpr int S = 4 * HT;
 #pragma unroll 1
@@ -1215,13 +1217,14 @@ extern "C" int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows
   const dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
   const int blocks32 = (rows + 31) / 32;
-  bool fused = false;
-  for (int g = 0; g < n_groups; ++g) fused = fused || groups[g].x == nullptr;
+  bool fused = false;   // (also set when activations are to be kept: only the whole-chain kernel writes them)
+  for (int g = 0; g < n_groups; ++g)
+    fused = fused || groups[g].x == nullptr || groups[g].in_out != nullptr || groups[g].hid_out != nullptr;
   int use_split = (dh == 128 && dout <= 64 && (long long)blocks32 * n_groups <= 1024 && (din == 64 || din == 128) &&
                    !fused)   // the fused-scatter prologue would be repeated by all 4 waves of a row block
                       ? 1
                       : 0;
-  if (const char* e = getenv("GN_MLP2_SPLIT")) use_split = atoi(e) != 0 && dh == 128 && dout <= 64;
+  if (const char* e = getenv("GN_MLP2_SPLIT")) use_split = atoi(e) != 0 && dh == 128 && dout <= 64 && !fused;
   if (use_split) {
     const dim3 grid(blocks32, n_groups);
     if (din == 64)

@@ -632,10 +632,13 @@ class ScatterSpec:
         self.feat, self.H, self.ori, self.sym, self.divisor = feat, H, ori, bool(sym), divisor
 
 
-def mlp2_grouped(items: Sequence[Tuple[object, dict, Optional[Tensor]]]) -> List[Tensor]:
+def mlp2_grouped(items: Sequence[Tuple[object, dict, Optional[Tensor]]], keep: Optional[List[dict]] = None
+                 ) -> List[Tensor]:
     """items = [(x (..., din) or ScatterSpec, pk{"W","bias","din","dh","dout"}, out or None)], same
     shapes and row stride for every group.  ``out`` may be a last-dim slice of a contiguous tensor
-    (row stride > dout): the kernel writes the column block in place."""
+    (row stride > dout): the kernel writes the column block in place.  ``keep`` (training): a list that
+    receives, per group, {"x": the MLP's input rows as evaluated (rows, din), "hid": relu(W0 x + b0) (rows, dh)}
+    — what the backward needs and the fused kernel otherwise never writes."""
     _groups(len(items))
     pk0 = items[0][1]
     din, dh, dout = pk0["din"], pk0["dh"], pk0["dout"]
@@ -674,7 +677,16 @@ def mlp2_grouped(items: Sequence[Tuple[object, dict, Optional[Tensor]]]) -> List
             ld0 = ldy
         elif ldy != ld0:
             raise ValueError("grouped mlp2: every group must have the same output row stride")
-        arr[g] = _lib.Mlp2Group(fields[0], fields[1], fields[2], y.data_ptr(), *fields[4:])
+        kp = (0, 0)
+        if keep is not None:
+            nrow = 1
+            for d_ in lead:
+                nrow *= int(d_)
+            kd = dict(x=torch.empty((nrow, din), dtype=like.dtype, device=like.device),
+                      hid=torch.empty((nrow, dh), dtype=like.dtype, device=like.device))
+            keep.append(kd)
+            kp = (kd["x"].data_ptr(), kd["hid"].data_ptr())
+        arr[g] = _lib.Mlp2Group(fields[0], fields[1], fields[2], y.data_ptr(), *fields[4:], *kp)
         outs.append(y)
     rows = 1
     for d_ in shape0:

@@ -300,6 +300,9 @@ typedef struct {
   const float* ori;
   int E;
   int sym;
+  float* in_out;    /* optional (training): the MLP's input rows as evaluated (rows, din) — with the fused
+                       scatter that is cat(H^T feat, ori)/N, which otherwise never exists in memory */
+  float* hid_out;   /* optional (training): the hidden activations relu(W0 x + b0) (rows, dh) */
 } gn_mlp2_group_t;
 int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
                 int N, float divisor, gn_stream_t stream);
