@@ -468,15 +468,25 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
 
     def node2edge(xs: Sequence[Tensor], idx: int) -> List[Tensor]:
         pks = [m._packed_n2e(idx) for m in mods]
-        xpq = ops.node_mlp_grouped([(x, pk) for x, pk in zip(xs, pks)])
-        return ops.node2edge_grouped([(xp, pq, H, pk["w2"], pk["b2"], sy)
-                                      for (xp, pq), H, pk, sy in zip(xpq, Hs, pks, syms)])
+        keep = [] if traces is not None else None
+        xpq = ops.node_mlp_grouped([(x, pk) for x, pk in zip(xs, pks)], keep)
+        edges = ops.node2edge_grouped([(xp, pq, H, pk["w2"], pk["b2"], sy)
+                                       for (xp, pq), H, pk, sy in zip(xpq, Hs, pks, syms)])
+        if traces is not None:      # kept for the backward: nothing of this round is re-computed there
+            for t, kd, (xp, pq), e in zip(traces, keep, xpq, edges):
+                t.n2e.append(dict(x1=kd["hid"], xp=xp, pq=pq, edges=e))
+        return edges
 
     def edge_mlp(stages, edges: Sequence[Tensor], want_dist: bool):
         # draws happen module by module, in the order given — the reference's RNG order per call site
         us = [next_u(i) for i in range(n)]
-        return ops.edge_mlp_gumbel_grouped([(e, u, st._packed(), st.bottleneck_dim, N if sy else 0, want_dist)
-                                            for e, u, st, sy in zip(edges, us, stages, syms)], _GUMBEL_TAU)
+        keep = [] if traces is not None else None
+        res = ops.edge_mlp_gumbel_grouped([(e, u, st._packed(), st.bottleneck_dim, N if sy else 0, want_dist)
+                                           for e, u, st, sy in zip(edges, us, stages, syms)], _GUMBEL_TAU, keep)
+        if traces is not None:
+            for t, kd in zip(traces, keep):
+                t.estage.append(kd)
+        return res
 
     def edge2node(edge_feats: Sequence[Tensor], oris: Sequence[Tensor], idx: int) -> List[Tensor]:
         aggs = [m.edge_aggregation_list[idx] for m in mods]

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -26,7 +26,7 @@ _SZ = ctypes.c_size_t
 _U64 = ctypes.c_ulonglong
 
 class NodeGroup(ctypes.Structure):      # gn_node_group_t
-    _fields_ = [("x", _P), ("W", _P), ("bias", _P), ("xp", _P), ("pq", _P)]
+    _fields_ = [("x", _P), ("W", _P), ("bias", _P), ("xp", _P), ("pq", _P), ("hid_out", _P)]
 
 
 class N2EGroup(ctypes.Structure):       # gn_n2e_group_t
@@ -35,7 +35,8 @@ class N2EGroup(ctypes.Structure):       # gn_n2e_group_t
 
 class EdgeGroup(ctypes.Structure):      # gn_edge_group_t
     _fields_ = [("edges", _P), ("U", _P), ("W", _P), ("bias", _P), ("edge_feat", _P), ("dist", _P),
-                ("philox_offset", _U64), ("rows", _I), ("K", _I), ("sym_N", _I)]
+                ("philox_offset", _U64), ("rows", _I), ("K", _I), ("sym_N", _I), ("keep_z1", _P), ("keep_z", _P),
+                ("keep_dh1", _P), ("keep_lgf", _P)]
 
 
 class GatherGroup(ctypes.Structure):    # gn_gather_group_t

@@ -162,6 +162,8 @@ class ModuleTrace:
         self.xs: List[Tensor] = [h]          # node features entering round j
         self.dists: List[Tensor] = []        # dist of round j (B,E,K)
         self.tails: List[dict] = []          # round j's closing MLP: {"x": cat(H^T feat, ori)/N, "hid": relu(layer 0)}
+        self.n2e: List[dict] = []            # round j: {"x1" hidden of node2edge_start_mlp, "xp", "pq", "edges"}
+        self.estage: List[dict] = []         # round j's edge MLP: {"z1", "z", "dh1", "lgf"}
 
 
 def _round_layers(mod, j: int):
@@ -273,27 +275,33 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
         gb.run()
 
     with torch.no_grad():
-        # ---------------- re-computation of what the fused forward did not keep ----------------
-        stage(lambda c: c.update(x1=gb.add(c["x2"], W(c["s0"]), new(c["B"] * c["N"], 256), tB=True, bias=b(c["s0"]),
-                                           relu=True)))
-        stage(lambda c: c.update(xp=gb.add(c["x1"], W(c["s1"]), new(c["B"] * c["N"], D), tB=True, bias=b(c["s1"]))))
-
-        # attention layer 0 on cat(x'_n, e0_e), split by linearity: P = W[:, :64] x' + b, Qn = W[:, 64:] x'
-        stage(lambda c: c.update(pq=gb.add(c["xp"], c["tw"]["Wpq"], new(c["B"] * c["N"], D), tB=True, bias=c["tw"]["bpq"])))
-        for c in S:
-            pk = c["mod"]._packed_n2e(j)      # (w2, b2) as the forward cached them: no host sync here
-            c["w2"], c["b2"] = pk["w2"], pk["b2"]
-        edges = ops.node2edge_grouped([(c["xp"].view(c["B"], c["N"], D), c["pq"].view(c["B"], c["N"], D), c["H"], c["w2"],
-                                        c["b2"], c["sym"]) for c in S])
-        for c, e in zip(S, edges):
-            c["edges"] = e.view(c["R"], D)
-        stage(lambda c: c.update(z1=gb.add(c["edges"], W(c["i"][0]), new(c["R"], 128), tB=True, bias=b(c["i"][0]),
-                                           relu=True)))
-        stage(lambda c: c.update(z=gb.add(c["z1"], W(c["i"][1]), new(c["R"], D), tB=True, bias=b(c["i"][1]))))
-
-        # hidden layers of MLP_distribution | MLP_factor side by side, then (logits | factor pre-activation)
-        stage(lambda c: c.update(dh1=gb.add(c["z"], c["tw"]["Wd0"], new(c["R"], 256), tB=True, bias=c["tw"]["bd0"], relu=True)))
-        stage(lambda c: c.update(lgf=gb.add(c["dh1"], c["tw"]["Wd1"], new(c["R"], _LGF_LD), tB=True, bias=c["tw"]["bd1"])))
+        # ---------------- what the fused forward kept (training mode writes these on request) ----------------
+        # The forward runs the pairwise module on unordered pairs; if this backward has to use ordered edge rows
+        # (N too large for the per-scene node2edge backward), its edge-row activations are re-computed instead.
+        kept = all(c["sym"] or c["H"] is not None and tr.H is not None for c, tr in zip(S, traces))
+        for c, tr in zip(S, traces):
+            c["w2"], c["b2"] = W(c["a1"])[0], b(c["a1"])
+            if kept:
+                a, e = tr.n2e[j], tr.estage[j]
+                c.update(x1=a["x1"], xp=a["xp"].view(-1, D), pq=a["pq"].view(-1, D), edges=a["edges"].view(c["R"], D),
+                         z1=e["z1"], z=e["z"], dh1=e["dh1"], lgf=e["lgf"])
+        if not kept:
+            stage(lambda c: c.update(x1=gb.add(c["x2"], W(c["s0"]), new(c["B"] * c["N"], 256), tB=True, bias=b(c["s0"]),
+                                               relu=True)))
+            stage(lambda c: c.update(xp=gb.add(c["x1"], W(c["s1"]), new(c["B"] * c["N"], D), tB=True, bias=b(c["s1"]))))
+            # attention layer 0 on cat(x'_n, e0_e), split by linearity: P = W[:, :64] x' + b, Qn = W[:, 64:] x'
+            stage(lambda c: c.update(pq=gb.add(c["xp"], c["tw"]["Wpq"], new(c["B"] * c["N"], D), tB=True, bias=c["tw"]["bpq"])))
+            edges = ops.node2edge_grouped([(c["xp"].view(c["B"], c["N"], D), c["pq"].view(c["B"], c["N"], D), c["H"], c["w2"],
+                                            c["b2"], c["sym"]) for c in S])
+            for c, e in zip(S, edges):
+                c["edges"] = e.view(c["R"], D)
+            stage(lambda c: c.update(z1=gb.add(c["edges"], W(c["i"][0]), new(c["R"], 128), tB=True, bias=b(c["i"][0]),
+                                               relu=True)))
+            stage(lambda c: c.update(z=gb.add(c["z1"], W(c["i"][1]), new(c["R"], D), tB=True, bias=b(c["i"][1]))))
+            # hidden layers of MLP_distribution | MLP_factor side by side, then (logits | factor pre-activation)
+            stage(lambda c: c.update(dh1=gb.add(c["z"], c["tw"]["Wd0"], new(c["R"], 256), tB=True, bias=c["tw"]["bd0"],
+                                                relu=True)))
+            stage(lambda c: c.update(lgf=gb.add(c["dh1"], c["tw"]["Wd1"], new(c["R"], _LGF_LD), tB=True, bias=c["tw"]["bd1"])))
         for c in S:
             # ef per edge row; for pair rows ef_ij + ef_ji (self-loop rows not doubled: the typed backward below
             # works with dfeat = the pair gather of d(H^T feat), which carries the self-loop's 2)

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256) void node_mlp_kernel(GroupTable<gn_node_group_
   f32x16 in[2], hid[8], o1[2], o2[2];
   load_rows<2>(G.x, GN_FEAT, rb.row_ld, rb.h, in);
   chain_linear<8, 2, true>(c, in, hid);
+  if (G.hid_out != nullptr) store_rows<8>(G.hid_out, 256, rb.row, rb.h, rb.live, hid);   // kept for the backward
   chain_linear<2, 8, false>(c, hid, o1);
   store_rows<2>(G.xp, GN_FEAT, rb.row, rb.h, rb.live, o1);
   chain_linear<2, 2, false>(c, o1, o2, true);
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge
     for (int t = 0; t < 4; ++t) {
       f32x16(&cur)[1] = (t & 1) ? hb : ha;     // tile t
       f32x16(&oth)[1] = (t & 1) ? ha : hb;     // tile t+1 (already produced, ReLU pending) / tile t+2 target
+      if (G.keep_z1 != nullptr) store_rows<1>(G.keep_z1 + 32 * t, 128, rb.row, h, rb.live, cur);   // (ReLU done)
       // S_t: z[0] += Wi1(0,t) h_t ; z[1] += Wi1(1,t) h_t      (ReLU of tile t+1 rides here when t == 2)
       mma_tile<1, 0>(w, w + 4 * kStep, ring, cur, z[0], [&](int s) { if (t == 2 && s == 1) relu16(oth[0]); });
       mma_tile<1, 4>(w + 4 * kStep, w + 8 * kStep, ring, cur, z[1]);
@@ -372,6 +374,7 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge
         w += 8 * kStep;
       }
     }
+    if (G.keep_z != nullptr) store_rows<2>(G.keep_z, GN_FEAT, rb.row, h, rb.live, z);
     // ---- pair B ----
     ha[0] = load_bias_tile(bd0, h);
     hb[0] = load_bias_tile(bd0 + 32, h);
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge
     for (int t = 0; t < 8; ++t) {
       f32x16(&cur)[1] = (t & 1) ? hb : ha;
       f32x16(&oth)[1] = (t & 1) ? ha : hb;
+      if (G.keep_dh1 != nullptr) store_rows<1>(G.keep_dh1 + 32 * t, 256, rb.row, h, rb.live, cur);
       // S_t: lg += Wd1(0,t) h_t  (4 steps; the ring slot alternates 0 / 4)
       if ((t & 1) == 0)
         mma_tile<1, 0>(w, w + 4 * kStep, ring, cur, lg[0], [&](int s) { if (t == 6 && s == 1) relu16(oth[0]); });
@@ -403,6 +407,7 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge
     fetch_uniforms(nullptr, pbase, seed, o1, K, rb.h, u1);
     if (G.sym_N > 0) fetch_uniforms(nullptr, pbase, seed, o2, K, rb.h, u2);
   }
+  if (G.keep_lgf != nullptr) store_rows<1>(G.keep_lgf, 32, rb.row, rb.h, rb.live, lg);
 
   // Epilogue.  Features 0..K-1 of `lg` are the logits of this lane's row, feature K the factor
   // pre-activation; a row's features are split over its two lanes (j, h=0) and (j, h=1).
@@ -996,6 +1001,7 @@ __global__ __launch_bounds__(256) void node_mlp_split_kernel(GroupTable<gn_node_
     if (s == 1) relu16(hid[1]);   // hid[1] is first read at step 4
   });
   mma_tile<2>(w1b, wpq, ring, hid, o1[1]);
+  if (G.hid_out != nullptr) store_rows<2>(G.hid_out + 64 * wave, 256, rb.row, h, rb.live, hid);   // tiles 2w, 2w+1
 #pragma unroll
   for (int o = 0; o < 2; ++o)
 #pragma unroll

@@ -331,9 +331,10 @@ def _groups(n: int) -> None:
         raise ValueError(f"1..{_lib.MAX_GROUPS} groups per launch, got {n}")
 
 
-def node_mlp_grouped(items: Sequence[Tuple[Tensor, dict]]) -> List[Tuple[Tensor, Tensor]]:
+def node_mlp_grouped(items: Sequence[Tuple[Tensor, dict]], keep: Optional[List[dict]] = None
+                     ) -> List[Tuple[Tensor, Tensor]]:
     """One launch for several modules: items = [(x (B,N,64), pk{"W","bias"})] with equal shapes;
-    returns [(x', pq)]."""
+    returns [(x', pq)].  ``keep`` (training) receives per group {"hid": relu(W0 x + b0) (rows, 256)}."""
     _groups(len(items))
     x0 = _req(items[0][0], "x", (None, None, FEAT))
     rows = x0.shape[0] * x0.shape[1]
@@ -343,7 +344,12 @@ def node_mlp_grouped(items: Sequence[Tuple[Tensor, dict]]) -> List[Tuple[Tensor,
         _req(x, "x", tuple(x0.shape))
         _same_device(x0, x)
         xp, pq = torch.empty_like(x), torch.empty_like(x)
-        arr[g] = _lib.NodeGroup(x.data_ptr(), pk["W"].data_ptr(), pk["bias"].data_ptr(), xp.data_ptr(), pq.data_ptr())
+        hid_ptr = 0
+        if keep is not None:
+            keep.append(dict(hid=torch.empty((rows, 256), dtype=x.dtype, device=x.device)))
+            hid_ptr = keep[-1]["hid"].data_ptr()
+        arr[g] = _lib.NodeGroup(x.data_ptr(), pk["W"].data_ptr(), pk["bias"].data_ptr(), xp.data_ptr(), pq.data_ptr(),
+                                hid_ptr)
         outs.append((xp, pq))
     flops = len(items) * rows * 2 * (64 * 256 + 256 * 64 + 64 * 64)
     with torch.cuda.device(x0.device), _Probed("node_mlp_kernel", flops):
@@ -411,13 +417,16 @@ class PhiloxNoise:
         self.seed, self.offset, self.counter = int(seed) & (2**64 - 1), int(offset), counter
 
 
-def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5) -> List[Tuple[Tensor, Optional[Tensor]]]:
+def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5, keep: Optional[List[dict]] = None
+                            ) -> List[Tuple[Tensor, Optional[Tensor]]]:
     """items = [(edges (B,E,64), U tensor (B,E,K) or PhiloxNoise, pk, K[, sym_N[, want_dist]])];
     returns [(edge_feat, dist)].  All PhiloxNoise entries of one call must share seed and counter.
 
     sym_N = N > 0: `edges` holds the (B, N(N+1)/2, 64) unordered-pair rows of the pairwise graph; U /
     the Philox positions and `dist` are those of the ORDERED (B, N*N, K) tensor; edge_feat is
-    (B, N(N+1)/2, K) = fac * (dist_ij + dist_ji).  want_dist=False skips the ordered dist output."""
+    (B, N(N+1)/2, K) = fac * (dist_ij + dist_ji).  want_dist=False skips the ordered dist output.
+    ``keep`` (training) receives per group the activations the kernel otherwise holds in registers:
+    {"z1" (rows,128), "z" (rows,64), "dh1" (rows,256), "lgf" (rows,32)}."""
     _groups(len(items))
     e0 = items[0][0]
     arr = (_lib.EdgeGroup * len(items))()
@@ -445,8 +454,13 @@ def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5) -> List[Tu
             u_ptr, off = U.data_ptr(), 0
         edge_feat = torch.empty((B, E, K), dtype=edges.dtype, device=edges.device)
         dist = torch.empty((B, Eo, K), dtype=edges.dtype, device=edges.device) if (want_dist or not sym_N) else None
+        kp = (0, 0, 0, 0)
+        if keep is not None:
+            mk = lambda w: torch.empty((B * E, w), dtype=edges.dtype, device=edges.device)
+            keep.append(dict(z1=mk(128), z=mk(64), dh1=mk(256), lgf=mk(32)))
+            kp = tuple(keep[-1][n].data_ptr() for n in ("z1", "z", "dh1", "lgf"))
         arr[g] = _lib.EdgeGroup(edges.data_ptr(), u_ptr, pk["W"].data_ptr(), pk["bias"].data_ptr(),
-                                edge_feat.data_ptr(), 0 if dist is None else dist.data_ptr(), off, B * E, K, sym_N)
+                                edge_feat.data_ptr(), 0 if dist is None else dist.data_ptr(), off, B * E, K, sym_N, *kp)
         outs.append((edge_feat, dist))
     flops = sum(int(a.rows) for a in arr) * 2 * (64 * 128 + 128 * 64 + 64 * 256 + 256 * 32)
     with torch.cuda.device(e0.device), _Probed("edge_mlp_gumbel_kernel", flops):

@@ -150,6 +150,7 @@ typedef struct {
   const float* bias;
   float* xp;
   float* pq;
+  float* hid_out;   /* optional (training): the hidden activations relu(W0 x + b0) (rows, 256) */
 } gn_node_group_t;
 int gn_node_mlp_f32(const gn_node_group_t* groups, int n_groups, int rows, gn_stream_t stream);
 
@@ -208,6 +209,13 @@ typedef struct {
   int rows;
   int K;
   int sym_N;
+  /* optional (training), all (rows, .): hidden of init_MLP (128), z (64), hidden of MLP_distribution |
+   * MLP_factor (256), and the 32-wide (logits | factor pre-activation | 0) tile — what the backward needs and
+   * the kernel otherwise keeps in registers */
+  float* keep_z1;
+  float* keep_z;
+  float* keep_dh1;
+  float* keep_lgf;
 } gn_edge_group_t;
 int gn_edge_mlp_gumbel_f32(const gn_edge_group_t* groups, int n_groups, float tau, unsigned long long seed,
                            const unsigned long long* offset_dev, gn_stream_t stream);

@@ -24,11 +24,13 @@ def _modules(seed, nmp=1):
 
 def _check(grads_hip, grads_ref, names):
     worst = 0.0
+    gmax = max(float(grads_ref[n].abs().max()) for n in names)
     for name in names:
         a, b = grads_hip[name], grads_ref[name]
         assert a is not None and b is not None, name
         assert a.shape == b.shape, (name, a.shape, b.shape)
-        scale = float(b.abs().max()) + 1e-3     # (softmax-shift directions have exactly zero gradient: absolute floor)
+        # own gradient scale, floored at 1 % of the model's largest (softmax-shift directions are exactly zero)
+        scale = max(float(b.abs().max()), 1e-2 * gmax)
         err = float((a.cpu() - b).abs().max()) / scale
         worst = max(worst, err)
         assert err <= 2e-3, (name, err, scale)

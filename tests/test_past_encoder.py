@@ -172,8 +172,11 @@ def test_encoder_training_gradients(which):
     used = [k for k, v in state.items() if v.grad is not None and float(v.grad.abs().max()) > 0]
     assert "input_fc.weight" in used and "pos_encoder.fc.weight" in used
     hip = dict(enc.named_parameters())
+    gmax = max(float(state[k].grad.abs().max()) for k in used)
     for k in used:
         a, b = hip[k].grad, state[k].grad
         assert a is not None, k
-        scale = float(b.abs().max()) + 1e-3      # (softmax-shift directions have exactly zero gradient: absolute floor)
+        # relative to the parameter's own gradient, floored at 1 % of the largest gradient in the model: some
+        # directions (the attention bias under a full softmax) have an exactly-zero gradient and only carry noise
+        scale = max(float(b.abs().max()), 1e-2 * gmax)
         assert float((a.cpu() - b).abs().max()) / scale <= 2e-3, k
