@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -98,9 +98,9 @@ SIGNATURES = {
     "gn_mlp2_f32": (_I, [ctypes.POINTER(Mlp2Group), _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "gn_gemm_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _F, _P]),
     "gn_gemm_grouped_f32": (_I, [ctypes.POINTER(GemmDesc), _I, _P]),
-    "gn_typed_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, ctypes.c_longlong, _I, _I, _P]),
+    "gn_typed_bwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, ctypes.c_longlong, _I, _I, _P]),
     "gn_axpby2d_f32": (_I, [_P, _I, _P, _I, ctypes.c_longlong, _I, _F, _F, _P]),
-    "gn_gumbel_ef_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _I, _I, _I, _F, _P]),
+    "gn_gumbel_ef_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _I, _I, _I, _F, _I, _P]),
     "gn_gumbel_bwd_f32": (_I, [_P, _P, _P, _P, _P, ctypes.c_longlong, _I, _I, _F, _I, _P]),
     "gn_node2edge_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "gn_philox_uniform_f32": (_I, [_P, _SZ, _U64, _U64, _P, _P]),

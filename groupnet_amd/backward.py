@@ -264,7 +264,7 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                       f=st.MLP_factor.layers, agg=agg, tw=_bwd_weights(mod, j), e0=e0, e1=e1,
                       tail=t.tails[j], dist=t.dists[j].reshape(-1, K), g_y=None if g_y is None else g_y.reshape(B * N, -1).contiguous(),
                       g_d=None if g_d is None else g_d.reshape(-1, K).contiguous(),
-                      pool=_Pool(npar + 2 * B * N * D + B * E * (K + 2 * D) + 4096, x.device)))
+                      pool=_Pool(npar + 2 * B * N * D + B * E * (2 * K + 4 + 2 * D) + 4096, x.device)))
     dev = S[0]["x"].device
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     gb = GemmBatch()
@@ -305,10 +305,12 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
         for c in S:
             # ef per edge row; for pair rows ef_ij + ef_ji (self-loop rows not doubled: the typed backward below
             # works with dfeat = the pair gather of d(H^T feat), which carries the self-loop's 2)
-            c["ef"] = new(c["R"], c["K"])
+            # (leading dimension padded to a multiple of 4, zero-filled: the GEMMs reading ef stay on the vector path)
+            c["Kp"] = (c["K"] + 3) // 4 * 4
+            c["ef"] = c["pool"].take(c["R"], c["Kp"])
             with torch.cuda.device(dev):
                 check(load().gn_gumbel_ef_f32(_p(c["dist"]), _p(c["lgf"]), _p(c["ef"]), c["R"], c["K"], _LGF_LD,
-                                              c["N"] if c["sym"] else 0, 1.0, stream_handle()), "gn_gumbel_ef_f32")
+                                              c["N"] if c["sym"] else 0, 1.0, c["Kp"], stream_handle()), "gn_gumbel_ef_f32")
             c["def"] = c["pool"].take(c["R"], c["K"])
             c["dx"] = None
 
@@ -338,7 +340,7 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
             stage(lambda c: c.update(T=gb.add(c["dfeat"], c["tw"]["W2cat"], new(c["R"], c["K"] * _HID))))
             for c in S:
                 with torch.cuda.device(dev):
-                    check(load().gn_typed_bwd_f32(_p(c["T"]), _p(c["Hc"]), _p(c["ef"]), _p(c["dfeat"]), _p(c["tw"]["b2mat"]),
+                    check(load().gn_typed_bwd_f32(_p(c["T"]), _p(c["Hc"]), _p(c["ef"]), c["Kp"], _p(c["dfeat"]), _p(c["tw"]["b2mat"]),
                                                   _p(c["def"]), c["R"], c["K"], _HID, stream_handle()), "gn_typed_bwd_f32")
             # (pair rows: the self-loop's eo = 2 ori, and the pair-form scatter below weighs every row once)
             # (K = K_types*128 is long and the output has few tiles: split K over workgroups, atomic accumulate)
@@ -356,7 +358,7 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                                                colsum=grads.setdefault(lin.bias, pool.take(*lin.bias.shape)))
                 gW1 = gb.add(c["T"], c["eo2"], pool.take(K * _HID, D), tA=True, accum=True,
                              colsum=c.setdefault("gb1", pool.take(K * _HID)))
-                gb2 = gb.add(c["ef"], c["dfeat"], pool.take(K, D), tA=True, accum=True)
+                gb2 = gb.add(c["ef"], c["dfeat"], pool.take(c["Kp"], D), tA=True, accum=True)     # rows >= K stay zero
                 for k, m in enumerate(c["agg"].agg_mlp):
                     l0, l1 = m.layers
                     grads[l0.weight], grads[l0.bias] = gW1[k * _HID:(k + 1) * _HID], c["gb1"][k * _HID:(k + 1) * _HID]

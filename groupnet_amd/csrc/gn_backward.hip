@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kB) void axpby2d_kernel(float* __restrict__ out, in
 // ef[r][k] = sigmoid(lgf[r][K]) * dist[r][k]   (edge_feat of MLP_dict_softmax from its saved pieces)
 __global__ __launch_bounds__(kB) void gumbel_ef_kernel(const float* __restrict__ dist, const float* __restrict__ lgf,
                                                        float* __restrict__ ef, long long rows, int K, int ldl,
-                                                       int sym_N, float diag_w) {
+                                                       int sym_N, float diag_w, int ld_ef) {
   const long long total = rows * K;
   const int P = sym_N > 0 ? gn_pair_count(sym_N) : 1;
   for (long long idx = (long long)blockIdx.x * kB + threadIdx.x; idx < total; idx += (long long)gridDim.x * kB) {
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(kB) void gumbel_ef_kernel(const float* __restrict__
     } else {
       d = dist[idx];
     }
-    ef[idx] = sig * d;
+    ef[r * ld_ef + k] = sig * d;
   }
 }
 
@@ -637,14 +637,14 @@ __global__ __launch_bounds__(kB) void gumbel_ef_kernel(const float* __restrict__
 __global__ __launch_bounds__(kB) void typed_bwd_kernel(float* __restrict__ T, const float* __restrict__ Hc,
                                                        const float* __restrict__ ef, const float* __restrict__ dfeat,
                                                        const float* __restrict__ b2, float* __restrict__ def,
-                                                       long long rows, int K, int hid) {
+                                                       long long rows, int K, int hid, int ld_ef) {
   const int lane = threadIdx.x & 63;
   for (long long r = (long long)blockIdx.x * (kB / 64) + (threadIdx.x >> 6); r < rows;
        r += (long long)gridDim.x * (kB / 64)) {
     const float g = dfeat[r * GN_FEAT + lane];
     for (int k = 0; k < K; ++k) {
       const size_t base = ((size_t)r * K + k) * hid;
-      const float e = ef[r * K + k];
+      const float e = ef[r * ld_ef + k];
       float v = g * b2[k * GN_FEAT + lane];
       for (int c = lane; c < hid; c += 64) {
         const float t = T[base + c], h = Hc[base + c];
@@ -798,24 +798,24 @@ extern "C" int gn_axpby2d_f32(float* out, int ldo, const float* a, int lda, long
 }
 
 extern "C" int gn_gumbel_ef_f32(const float* dist, const float* lgf, float* ef, long long rows, int K, int ldl,
-                                int sym_N, float diag_w, gn_stream_t stream) {
+                                int sym_N, float diag_w, int ld_ef, gn_stream_t stream) {
   GN_REQUIRE_PTR(dist);
   GN_REQUIRE_PTR(lgf);
   GN_REQUIRE_PTR(ef);
-  if (rows <= 0 || K < 1 || ldl <= K || sym_N < 0) return GN_ERR_SHAPE;
+  if (rows <= 0 || K < 1 || ldl <= K || sym_N < 0 || ld_ef < K) return GN_ERR_SHAPE;
   if (sym_N > 0 && rows % gn_pair_count(sym_N) != 0) return GN_ERR_SHAPE;
   hipLaunchKernelGGL(gumbel_ef_kernel, dim3(cap_grid(rows * K, kB)), dim3(kB), 0, (hipStream_t)stream, dist, lgf, ef,
-                     rows, K, ldl, sym_N, diag_w);
+                     rows, K, ldl, sym_N, diag_w, ld_ef);
   return gn_check_launch();
 }
 
-extern "C" int gn_typed_bwd_f32(float* T, const float* Hc, const float* ef, const float* dfeat, const float* b2,
-                                float* def, long long rows, int K, int hid, gn_stream_t stream) {
+extern "C" int gn_typed_bwd_f32(float* T, const float* Hc, const float* ef, int ld_ef, const float* dfeat,
+                                const float* b2, float* def, long long rows, int K, int hid, gn_stream_t stream) {
   const void* ptrs[] = {T, Hc, ef, dfeat, b2, def};
   for (const void* p : ptrs)
     if (p == nullptr) return GN_ERR_NULL;
-  if (rows <= 0 || K < 1 || hid < 64 || hid % 64) return GN_ERR_SHAPE;
+  if (rows <= 0 || K < 1 || hid < 64 || hid % 64 || ld_ef < K) return GN_ERR_SHAPE;
   hipLaunchKernelGGL(typed_bwd_kernel, dim3(cap_grid(rows, kB / 64, 8192)), dim3(kB), 0, (hipStream_t)stream, T, Hc, ef,
-                     dfeat, b2, def, rows, K, hid);
+                     dfeat, b2, def, rows, K, hid, ld_ef);
   return gn_check_launch();
 }

@@ -368,14 +368,15 @@ int gn_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
 int gn_axpby2d_f32(float* out, int ldo, const float* a, int lda, long long rows, int cols, float alpha,
                    float beta, gn_stream_t stream);
 /* ef[r][k] = sigmoid(lgf[r][K]) * dist[r][k]: edge_feat of MLP_dict_softmax from dist and the factor
- * pre-activation (column K of lgf (rows, ldl)). */
+ * pre-activation (column K of lgf (rows, ldl)); ef has leading dimension ld_ef >= K (a multiple of 4 keeps
+ * the GEMMs that read it on the vector path). */
 int gn_gumbel_ef_f32(const float* dist, const float* lgf, float* ef, long long rows, int K, int ldl, int sym_N,
-                     float diag_w, gn_stream_t stream);
+                     float diag_w, int ld_ef, gn_stream_t stream);
 /* Middle of the typed aggregation MLP's backward (model/MS_HGNN_batch.py:264-265), all K types of a row at
  * once: T (rows, K*hid) holds dfeat W2cat, Hc (rows, K*hid) the hidden activations; writes
  * def[r][k] = <T[r,k,:], Hc[r,k,:]> + <dfeat[r], b2[k]> and T[r,k,:] <- ef[r][k] * T[r,k,:] * (Hc > 0). */
-int gn_typed_bwd_f32(float* T, const float* Hc, const float* ef, const float* dfeat, const float* b2, float* def,
-                     long long rows, int K, int hid, gn_stream_t stream);
+int gn_typed_bwd_f32(float* T, const float* Hc, const float* ef, int ld_ef, const float* dfeat, const float* b2,
+                     float* def, long long rows, int K, int hid, gn_stream_t stream);
 int gn_gumbel_bwd_f32(const float* dist, const float* lgf, const float* def, const float* gdist, float* dlgf,
                       long long rows, int K, int ldl, float tau, int sym_N, gn_stream_t stream);
 int gn_node2edge_bwd_f32(const float* xp, const float* pq, const float* H, const float* w2, const float* b2,
