@@ -257,3 +257,42 @@ def test_hip_backward_matches_reference_gradients(name):
             if f"{prefix}_g/{n}" in c:
                 full = torch.from_numpy(c[f"{prefix}_g/{n}"])
                 assert float((g.cpu() - full).abs().max()) <= 2e-3 * float(full.abs().max()) + 1e-6, (prefix, n)
+
+
+def test_full_size_backward_is_additive_over_shards():
+    """BASELINE size (B=512, N=11, scales {2,5,11}), size-independent properties of the backward: scenes are
+    independent, so dL/df of a scene does not depend on what else is in the batch, and every parameter
+    gradient of the full batch is the sum of the two half-batch gradients (same weights, same noise rows).
+    Kernel forms depend on the launch size, so pre-activations differ in the last bits between the runs; with
+    ~1e7 hidden units per batch a handful of ReLUs sit within that distance of zero and flip, each changing one
+    unit's contribution.  The statement is therefore "equal except for a few such units": dL/df agrees on all
+    but <= 0.2 % of its entries, parameter gradients agree to 2 % in Frobenius norm (measured: 133 of 360 448
+    entries, worst parameter 0.9 %; two runs of the same batch agree to 3e-5)."""
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    dev = torch.device("cuda:0")
+    torch.manual_seed(12)
+    B, N = 512, 11
+    blk = MultiScaleHGNN([2, 5, 11]).to(dev).train()
+    f = torch.randn(B, N, 64, device=dev)
+    R = torch.randn(B, N, blk.out_features, device=dev)
+    noise = [[torch.rand(s, device=dev)] for s in blk.noise_shapes(B, N)]
+
+    def run(lo, hi):
+        for p in blk.parameters():
+            p.grad = None
+        x = f[lo:hi].clone().requires_grad_(True)
+        out, _ = blk(x, noise_u=[[u[0][lo:hi].contiguous()] for u in noise])
+        (out * R[lo:hi]).sum().backward()
+        return x.grad, {n: p.grad.clone() for n, p in blk.named_parameters() if p.grad is not None}
+
+    g_full, w_full = run(0, B)
+    g_a, w_a = run(0, B // 2)
+    g_b, w_b = run(B // 2, B)
+    gscale = float(g_full.abs().max())
+    d = (torch.cat((g_a, g_b)) - g_full).abs()
+    assert float((d > 1e-4 * gscale).float().mean()) <= 2e-3         # all but a few flipped-ReLU neighbourhoods agree
+    assert float(d.max()) <= 2e-2 * gscale
+    assert len(w_full) >= 200
+    for n, v in w_full.items():
+        err = float((w_a[n] + w_b[n] - v).norm()) / (float(v.norm()) + 1e-12)
+        assert err <= 2e-2, (n, err)
