@@ -14,6 +14,8 @@
 //   gn_node2edge_bwd_f32   back through the attention-weighted pooling (one wave per hyperedge, like the
 //                          forward; node rows are shared by edges, so their gradients are atomic adds).
 // Gather and scatter are each other's adjoints and reuse the forward kernels.
+#include <stdlib.h>
+
 #include "gn_common.hpp"
 
 namespace {
@@ -704,8 +706,9 @@ extern "C" int gn_gemm_grouped_f32(const gn_gemm_desc_t* descs, int n, gn_stream
     const int gm = (d.M + BM - 1) / BM, gn = (d.N + BN - 1) / BN;
     int splits = 1;
     if (d.flags & GN_GEMM_ACCUM) {   // long K over few tiles: split K, partial sums by atomics
+      // (swept on the whole training step at B=512: >= 256 rows per split, ~512 workgroups per problem)
       splits = (512 + gm * gn - 1) / (gm * gn);
-      const int max_splits = (d.K + 511) / 512;
+      const int max_splits = (d.K + 255) / 256;
       splits = splits > max_splits ? max_splits : splits;
     }
     int kchunk = ((d.K + splits - 1) / splits + BK - 1) / BK * BK;
