@@ -118,7 +118,9 @@ class MLP(nn.Module):
 
     Inside the MS-HGNN modules an MLP is only a parameter container — the fused HIP chains read
     its weights.  Called on its own (the reference's L3 model imports it for unrelated heads,
-    model/GroupNet_nba.py:9,31-32) it is ordinary PyTorch layer math on whatever device it is on.
+    model/GroupNet_nba.py:9,31-32) every Linear runs on the HIP GEMM (`groupnet_amd.linear.hip_linear`,
+    differentiable); activations / dropout between the layers are elementwise torch ops.  GPU tensors only,
+    like everything else in this package.
     """
 
     def __init__(self, input_dim, output_dim, hidden_size=(1024, 512), activation='relu', discrim=False,
@@ -134,9 +136,11 @@ class MLP(nn.Module):
         self.dropout = dropout
 
     def forward(self, x):
+        from .linear import hip_linear
+        ops._req(x, "x")
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
-            x = layer(x)
+            x = hip_linear(x, layer)
             if i != last:
                 x = self.activation(x)
                 if self.dropout != -1:

@@ -138,16 +138,12 @@ def test_product_never_touches_the_oracle():
                 assert "ms_hgnn_oracle" not in text, fn
 
 
-def test_mlp_standalone_is_plain_layer_math():
+def test_mlp_standalone_has_no_cpu_path_either():
+    """`MLP` called on its own (the reference imports it for heads outside the path) runs its Linears on the
+    HIP GEMM; like every other module it refuses CPU tensors instead of falling back to torch math."""
     from groupnet_amd import MLP
     torch.manual_seed(0)
     m = MLP(8, 3, hidden_size=(16, 5))
-    x = torch.randn(4, 8)
-    y = m(x)
-    z = x
-    for i, l in enumerate(m.layers):
-        z = l(z)
-        if i < 2:
-            z = torch.relu(z)
-    assert torch.equal(y, z)
-    assert torch.all(MLP(8, 3, hidden_size=(4,), discrim=True)(x).sigmoid() > 0)
+    assert [tuple(l.weight.shape) for l in m.layers] == [(16, 8), (5, 16), (3, 5)]
+    with pytest.raises(ValueError):
+        m(torch.randn(4, 8))

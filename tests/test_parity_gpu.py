@@ -246,9 +246,10 @@ def test_mlp2_shapes_and_pack():
                                 (128, 256, 7, 1)]:
         m = MLP(din, dout, hidden_size=(dh,))
         x = torch.randn(rows, din)
-        with torch.no_grad():
-            y_ref = m(x)
         l0, l1 = m.layers
+        with torch.no_grad():      # plain torch fp32 layer math on the CPU as the reference of this op
+            y_ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x, l0.weight, l0.bias)),
+                                               l1.weight, l1.bias)
         pk = dict(W=ops.pack_stream([l0.weight.detach().to(dev()), l1.weight.detach().to(dev())]),
                   bias=ops.bias_stream([l0.bias.detach().to(dev()), l1.bias.detach().to(dev())]),
                   din=din, dh=dh, dout=dout)
@@ -801,3 +802,30 @@ def test_pack_plan_equals_matrix_by_matrix_packing():
             with torch.no_grad():          # in-place update (an optimizer step): the next access re-packs
                 for p in m.parameters():
                     p.add_(torch.randn_like(p) * 0.1)
+
+
+def test_mlp_standalone_on_the_hip_gemm():
+    """`MLP.forward` on its own (model/MS_HGNN_batch.py:220-229: Linear, activation between layers, optional
+    final sigmoid) against plain torch fp32 layer math on the same device, forward and gradients; odd widths
+    take the ragged GEMM kernel."""
+    from groupnet_amd import MLP
+    torch.manual_seed(4)
+    for kw, shape in ((dict(input_dim=8, output_dim=3, hidden_size=(16, 5)), (37, 8)),
+                      (dict(input_dim=128, output_dim=64, hidden_size=(128,)), (5, 11, 128)),
+                      (dict(input_dim=20, output_dim=1, hidden_size=(32,), discrim=True, activation='sigmoid'), (9, 20))):
+        m = MLP(**kw).to(dev())
+        x = torch.randn(*shape, device=dev(), requires_grad=True)
+        y = m(x)
+        z = x
+        for i, l in enumerate(m.layers):
+            z = torch.nn.functional.linear(z, l.weight, l.bias)
+            if i != len(m.layers) - 1:
+                z = m.activation(z)
+            elif m.sigmoid is not None:
+                z = torch.sigmoid(z)
+        assert float((y - z).abs().max()) <= 1e-5 * max(1.0, float(z.abs().max()))
+        R = torch.randn_like(y)
+        gx, *gw = torch.autograd.grad((y * R).sum(), [x, *m.parameters()])
+        rx, *rw = torch.autograd.grad((z * R).sum(), [x, *m.parameters()])
+        for a, b in zip([gx, *gw], [rx, *rw]):
+            assert float((a - b).abs().max()) <= 1e-4 * max(1e-3, float(b.abs().max()))
