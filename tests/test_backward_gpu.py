@@ -296,3 +296,20 @@ def test_full_size_backward_is_additive_over_shards():
     for n, v in w_full.items():
         err = float((w_a[n] + w_b[n] - v).norm()) / (float(v.norm()) + 1e-12)
         assert err <= 2e-2, (n, err)
+
+
+def test_graphed_train_step_with_adam():
+    """The reference trains with Adam (train_hyper_nba.py); `capturable=True` keeps its step inside the graph."""
+    from groupnet_amd.graphs import GraphedTrainStep
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B, N = 8, 11
+    blk = MultiScaleHGNN([5, 11]).to(dev).train()
+    f = torch.randn(B, N, 64, device=dev)
+    tgt = torch.randn(B, N, blk.out_features, device=dev)
+    opt = torch.optim.Adam(blk.parameters(), lr=1e-3, capturable=True)
+    step = GraphedTrainStep(blk, opt, lambda out, H, t: ((out - t) ** 2).mean(), B, N, target_shapes=[tuple(tgt.shape)],
+                            seed=3, warmup=2)
+    losses = [float(step(f, tgt)) for _ in range(12)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0]
