@@ -17,8 +17,8 @@ wanted) the embedding runs layer by layer on the HIP GEMM with its HIP backward,
 autograd path of `groupnet_amd.backward`.  `FutureEncoder` is the same encoder at the
 reference's second call site plus its output head.
 
-Parity of this block is UNPINNED against the reference (GroupNet_nba.py cannot be imported in the build
-container; see oracle/past_encoder_oracle.py); it is tested against that restatement.
+Parity: pinned by goldens the reference's own `PastEncoder` / `FutureEncoder` classes produced
+(tests/golden/make_golden_past_encoder.py; tests/test_past_encoder.py).
 """
 from __future__ import annotations
 

@@ -1,14 +1,20 @@
-"""CPU oracle for the PastEncoder front-end.  TEST INFRASTRUCTURE ONLY.
+"""CPU oracle for the trajectory encoders.  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: `model/GroupNet_nba.py` cannot be imported in the build container (its line 2 imports
-`tkinter`, `model/utils.py:8` imports `glob2`; neither package exists here and libraries the image lacks
-stay absent), and the reference holds no fixtures for this block.  This file is therefore a restatement
-written from reading the source (each function cites the lines it follows), checked only for internal
-consistency (the composed affine map of the HIP path == this layer-by-layer evaluation).  The
-MS-HGNN modules it calls ARE pinned (oracle/ms_hgnn_oracle.py).
+PINNED: `model/GroupNet_nba.py` cannot be imported as a module in the build container (its line 2 imports
+`tkinter`, `model/utils.py:8` imports `glob2`; neither exists here), but the classes this file restates use
+neither.  `tests/golden/make_golden_past_encoder.py` executes the reference's own, unmodified class definitions
+(`PositionalAgentEncoding`, `PastEncoder`, `MLP2`, `FutureEncoder`, `initialize_weights`) straight from
+/root/reference and stores their outputs; `tests/test_past_encoder.py` checks this restatement against them
+(<= 2e-6): `PastEncoder.forward` for hyper_scales [5,11] and [2,5,11], `FutureEncoder.forward` for
+hyper_scales [] — the only configuration in which the reference's FutureEncoder runs at all (with a hyper
+scale it raises on its own 3-tuple unpack, model/GroupNet_nba.py:408-413).  FutureEncoder WITH hyper scales is
+therefore pinned only piecewise (its front-end, modules and head are each pinned; their composition follows
+the "take node_feat" reading of :408-413).  Training-mode dropout masks are unpinned (the reference draws them
+on the CPU generator).
 
-What it restates: `PositionalAgentEncoding` (model/GroupNet_nba.py:156-195) and the embedding lines of
-`PastEncoder.forward` (:266-286) in eval mode (dropout is the identity).
+What it restates: `PositionalAgentEncoding` (model/GroupNet_nba.py:156-195), the embedding lines of
+`PastEncoder.forward` (:266-286) in eval mode (dropout is the identity), the module calls and concat
+(:290-311), and `FutureEncoder.forward` (:393-438).
 """
 from __future__ import annotations
 
