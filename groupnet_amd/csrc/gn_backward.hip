@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kB) void node2edge_bwd_kernel(const float* __restri
   float sum = 0.f;
   for (int m = lane; m < cnt; m += 64) sum += expf(s_att[m] * s_h[m] - mx);
   sum = gn_wave_sum(sum);
-  sum += (float)(N - cnt) * expf(0.f - mx);
+  sum += gn_nonmember_sum(N - cnt, mx);
   // sum_j p_j dp_j over members (dp = dw * h; non-members have dp = 0)
   float pd = 0.f;
   for (int m = lane; m < cnt; m += 64) {
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(kB) void node2edge_bwd_scene_kernel(
     float sum = 0.f;
     for (int m = lane; m < cnt; m += 64) sum += expf(s_att[m] * s_h[m] - mx);
     sum = gn_wave_sum(sum);
-    sum += (float)(N - cnt) * expf(0.f - mx);
+    sum += gn_nonmember_sum(N - cnt, mx);
     float pd = 0.f;
     for (int m = lane; m < cnt; m += 64) pd += expf(s_att[m] * s_h[m] - mx) / sum * s_dw[m] * s_h[m];
     pd = gn_wave_sum(pd);

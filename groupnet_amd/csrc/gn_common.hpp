@@ -45,6 +45,13 @@ __device__ __forceinline__ float gn_wave_max(float v) {
   return v;
 }
 
+// softmax(att*H) runs over ALL N nodes (model/MS_HGNN_batch.py:366-367): the `others` non-members each add
+// exp(0 - mx).  With others == 0 the running maximum mx may be far below zero, exp(0 - mx) overflows and
+// 0 * inf would poison the sum: the term is then absent, not multiplied by zero.
+__device__ __forceinline__ float gn_nonmember_sum(int others, float mx) {
+  return others > 0 ? (float)others * expf(0.f - mx) : 0.f;
+}
+
 // Kernels that may ask for more than 64 KiB of dynamic LDS must opt in once per process.
 template <typename K>
 static inline void gn_allow_big_lds(K kernel) {

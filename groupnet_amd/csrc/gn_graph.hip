@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_kernel(GroupTable<gn_n2e_gro
   float sum = 0.f;
   for (int m = lane; m < cnt; m += 64) sum += expf(s_att[m] * s_h[m] - mx);
   sum = gn_wave_sum(sum);
-  sum += (float)(N - cnt) * expf(0.f - mx);
+  sum += gn_nonmember_sum(N - cnt, mx);
   // edges[e] = sum_n (softmax_n * H[e,n]) * x'_n ; lane = feature
   float acc = 0.f;
   for (int m = 0; m < cnt; ++m) {
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
         const float v = 2.f * ai;
         const float mx = N > 1 ? fmaxf(v, 0.f) : v;
         const float ev = expf(v - mx);
-        const float sum = ev + (float)(N - 1) * expf(0.f - mx);
+        const float sum = ev + gn_nonmember_sum(N - 1, mx);
         s_w[2 * threadIdx.x] = ev / sum * 2.f;
         s_w[2 * threadIdx.x + 1] = 0.f;
       } else {
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
         aj += b2v;
         const float mx = N > 2 ? fmaxf(fmaxf(ai, aj), 0.f) : fmaxf(ai, aj);
         const float ei = expf(ai - mx), ej = expf(aj - mx);
-        const float sum = (ei + ej) + (float)(N - 2) * expf(0.f - mx);
+        const float sum = (ei + ej) + gn_nonmember_sum(N - 2, mx);
         s_w[2 * threadIdx.x] = ei / sum;
         s_w[2 * threadIdx.x + 1] = ej / sum;
       }

@@ -29,7 +29,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .MS_HGNN_batch import (MS_HGNN_hyper, MS_HGNN_oridinary, _draw_uniform, _needs_grad, _param_key,
+from .MS_HGNN_batch import (MS_HGNN_hyper, MS_HGNN_oridinary, _NoiseState, _draw_uniform, _needs_grad, _param_key,
                             run_message_passing)
 
 Tensor = torch.Tensor
@@ -137,10 +137,22 @@ class _TrajectoryEncoder(nn.Module):
         tf_in = hip_linear(inputs.reshape(B * N * T, -1), self.input_fc)                             # :269
         pe = self.pos_encoder.pe[:T].to(inputs.dtype).repeat(B * N, 1)                               # :177-178
         x = hip_linear(torch.cat([tf_in, pe], dim=-1), self.pos_encoder.fc)                          # :190-192
-        x = self.pos_encoder.dropout(x)                                                              # :195
+        x = self._dropout(x)                                                                         # :195
         ftraj = hip_linear(x.view(B * N, T * D), self.input_fc2)                                     # :276-277
         cat = self._category(N, inputs.dtype, inputs.device).repeat(B, 1)                            # :262
         return hip_linear(torch.cat((ftraj, cat), dim=-1), self.input_fc3).view(B, N, D)             # :279-280
+
+    def _dropout(self, x: Tensor) -> Tensor:
+        """nn.Dropout of the positional encoder.  Host noise mode (the default, reference contract): the mask is
+        drawn exactly as the reference's CPU module draws it — torch's dropout on a CPU tensor of the same shape,
+        global CPU generator, before the modules' uniforms — and uploaded; device mode: torch's device generator."""
+        drop = self.pos_encoder.dropout
+        if not (self.training and drop.p > 0):
+            return x
+        if _NoiseState.mode == "host":
+            mask = torch.nn.functional.dropout(torch.ones(x.shape, dtype=x.dtype), drop.p, True)
+            return x * mask.to(x.device, non_blocking=True)
+        return drop(x)
 
     def _encode(self, inputs: Tensor, B: int, N: int) -> Tuple[Tensor, Optional[Tensor]]:
         """(final_feature (B,N,64*(2+S)), new_H): embedding, affinity, incidences, all modules, concat."""

@@ -47,11 +47,13 @@ def reference_classes():
     return ns["PastEncoder"], ns["FutureEncoder"]
 
 
-def run(name, scales, B, seed):
+def run(name, scales, B, seed, train=False):
+    """train=True: the module in training mode, i.e. with the dropout of the positional encoder active
+    (model/GroupNet_nba.py:195; mask drawn on the global CPU generator before the modules' uniforms)."""
     PastEncoder, _ = reference_classes()
     torch.manual_seed(seed)
     args = types.SimpleNamespace(hidden_dim=64, hyper_scales=list(scales), past_length=5)
-    enc = PastEncoder(args).eval()
+    enc = PastEncoder(args).train(train)
     with torch.no_grad():      # default init gives an almost constant embedding and flat attention: spread them out
         for p in (enc.input_fc.weight, enc.input_fc2.weight, enc.input_fc3.weight, enc.pos_encoder.fc.weight):
             p.mul_(3.0)
@@ -108,4 +110,5 @@ def run_future(name, B, seed):
 if __name__ == "__main__":
     run_future("noscale_b6", 6, 703)
     run("s5_11_b9", [5, 11], 9, 701)
+    run("train_s5_11_b6", [5, 11], 6, 704, train=True)
     run("s2_5_11_b4", [2, 5, 11], 4, 702)

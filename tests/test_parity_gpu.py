@@ -829,3 +829,43 @@ def test_mlp_standalone_on_the_hip_gemm():
         rx, *rw = torch.autograd.grad((z * R).sum(), [x, *m.parameters()])
         for a, b in zip([gx, *gw], [rx, *rw]):
             assert float((a - b).abs().max()) <= 1e-4 * max(1e-3, float(b.abs().max()))
+
+
+def test_full_membership_softmax_with_large_negative_logits():
+    """softmax(att*H) over all N nodes: when every node is a member (scale == N, or the pairwise graph at
+    N <= 2) there is no exp(0) term, and with strongly negative logits exp(0 - max) overflows — the kernels must
+    drop the term rather than compute 0 * inf.  (Found by the training-mode PastEncoder golden, whose
+    un-normalised embeddings drive the attention logits to about -150.)"""
+    from groupnet_amd import ops
+    torch.manual_seed(8)
+    pair, hyper = build_modules(1)
+    for N, s in ((11, 11), (2, 2), (1, 1)):
+        hyper.scale = s
+        for m in (pair, hyper):
+            m.cpu()
+            with torch.no_grad():           # strongly negative attention logits for every node
+                m.attention_mlp[0].layers[1].bias.fill_(-400.0)
+        sp = {k: v.detach().clone() for k, v in pair.state_dict().items()}
+        sh = {k: v.detach().clone() for k, v in hyper.state_dict().items()}
+        h = torch.randn(3, N, 64)
+        corr = O.affinity(h)
+        Up = [torch.rand(x) for x in O.noise_shapes(3, N, None)]
+        Uh = [torch.rand(x) for x in O.noise_shapes(3, N, s)]
+        nf_p, fac_p = O.ms_hgnn_pairwise_forward(sp, h, Up, decomposed=True)
+        nf_h, fac_h, H = O.ms_hgnn_hyper_forward(sh, h, corr, s, Uh, decomposed=True)
+        assert bool(torch.isfinite(nf_p).all()) and bool(torch.isfinite(nf_h).all())
+        pair.to(dev()), hyper.to(dev())
+        with torch.no_grad():
+            a, b = pair(h.to(dev()), noise_u=[u.to(dev()) for u in Up])
+            c, d, H2 = hyper(h.to(dev()), corr.to(dev()), noise_u=[u.to(dev()) for u in Uh])
+        assert maxerr(a, nf_p.numpy()) <= TOL and maxerr(b, fac_p.numpy()) <= TOL, N
+        assert maxerr(c, nf_h.numpy()) <= TOL and maxerr(d, fac_h.numpy()) <= TOL, N
+        # and the backward of the same rows stays finite
+        for m in (pair, hyper):
+            m.train()
+        x = h.to(dev()).requires_grad_(True)
+        (pair(x, noise_u=[u.to(dev()) for u in Up])[0].sum() + hyper(x, corr.to(dev()), noise_u=[u.to(dev()) for u in Uh])[0].sum()).backward()
+        assert bool(torch.isfinite(x.grad).all())
+        assert all(bool(torch.isfinite(p.grad).all()) for m in (pair, hyper) for p in m.parameters() if p.grad is not None)
+        for m in (pair, hyper):
+            m.eval()

@@ -262,3 +262,23 @@ def test_future_encoder_matches_reference_golden():
         got = enc(torch.from_numpy(c["x"]).to(dev), B, 11, torch.from_numpy(c["past"]).to(dev))
     want = torch.from_numpy(c["q_z_params"])
     assert float((got.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
+def test_past_encoder_training_mode_matches_reference_golden():
+    """Training mode (dropout of the positional encoder active): with host noise the HIP encoder draws the
+    dropout mask and the Gumbel uniforms from the global CPU generator in the reference's order, so a seeded
+    forward reproduces the reference module's training-mode output."""
+    from groupnet_amd.past_encoder import PastEncoder
+    c, sd = _pe_golden("train_s5_11_b6")
+    B, scales = int(c["B"]), [int(s) for s in c["scales"]]
+    enc = PastEncoder(types.SimpleNamespace(hidden_dim=64, hyper_scales=scales, past_length=5))
+    enc.load_state_dict(sd, strict=True)
+    dev = torch.device("cuda:0")
+    enc.to(dev).train()
+    torch.manual_seed(int(c["seed"]))
+    out, new_H = enc(torch.from_numpy(c["x"]).to(dev), B, 11)
+    assert out.requires_grad
+    want = torch.from_numpy(c["output_feature"])
+    assert float((out.detach().cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert torch.equal(new_H.cpu(), torch.from_numpy(c["new_H"]))
