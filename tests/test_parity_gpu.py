@@ -869,3 +869,48 @@ def test_full_membership_softmax_with_large_negative_logits():
         assert all(bool(torch.isfinite(p.grad).all()) for m in (pair, hyper) for p in m.parameters() if p.grad is not None)
         for m in (pair, hyper):
             m.eval()
+
+
+@pytest.mark.parametrize("in_scale,w_scale", [(1e-3, 1.0), (30.0, 1.0), (1.0, 12.0), (30.0, 6.0), (200.0, 3.0)])
+def test_modules_under_extreme_magnitudes(in_scale, w_scale):
+    """Un-normalised inputs and sharp attention / distribution heads (saturated softmax, sigmoid and ReLU
+    regimes, logits in the hundreds, one all-zero agent): the HIP modules against the oracle, relative to the
+    output scale; nothing may turn into inf / NaN.  (Probabilities: 1e-4 — a logit of magnitude 10^3 carries
+    1e-4 of fp32 rounding, which the exponential turns into that relative error.)"""
+    torch.manual_seed(int(in_scale * 7 + w_scale))
+    pair, hyper = build_modules(1)
+    with torch.no_grad():
+        for m in (pair, hyper):
+            for n_, p in m.named_parameters():
+                if "attention_mlp" in n_ or "MLP_distribution" in n_ or "MLP_factor" in n_:
+                    p.mul_(w_scale)
+    B, N = 6, 11
+    h = torch.randn(B, N, 64) * in_scale
+    h[1, 3] = 0.0        # a zero feature row: its affinities are all exactly 0, i.e. its top-k is one big tie, whose
+    #                      order is implementation-defined — the incidence is therefore taken from the oracle
+    corr = O.affinity(h)
+    sp = {k: v.detach().clone() for k, v in pair.state_dict().items()}
+    sh = {k: v.detach().clone() for k, v in hyper.state_dict().items()}
+    pair.to(dev()), hyper.to(dev())
+    Up = [torch.rand(x) for x in O.noise_shapes(B, N, None)]
+    nf_p, fac_p = O.ms_hgnn_pairwise_forward(sp, h, Up, decomposed=True)
+    with torch.no_grad():
+        a, b = pair(h.to(dev()), noise_u=[u.to(dev()) for u in Up])
+    assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+    assert maxerr(a, nf_p.numpy()) <= 2e-5 * max(1.0, float(nf_p.abs().max()))
+    assert maxerr(b, fac_p.numpy()) <= 1e-4
+    for s in (2, 5, 11):
+        hyper.scale = s
+        Uh = [torch.rand(x) for x in O.noise_shapes(B, N, s)]
+        nf_h, fac_h, H = O.ms_hgnn_hyper_forward(sh, h, corr, s, Uh, decomposed=True)
+        with torch.no_grad():
+            c, d, H2 = hyper(h.to(dev()), corr.to(dev()), noise_u=[u.to(dev()) for u in Uh], H=H.to(dev()))
+            H3 = hyper.init_adj_attention(h.to(dev()), corr.to(dev()), scale_factor=s).cpu()
+        tied = torch.zeros(B, N, dtype=torch.bool)
+        tied[1, 3] = True
+        if s != N:
+            assert torch.equal(H3[~tied], H[~tied])          # every row but the all-tied one
+            assert float(H3[1, 3].sum()) == float(s)
+        assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(d).all())
+        assert maxerr(c, nf_h.numpy()) <= 2e-5 * max(1.0, float(nf_h.abs().max())), s
+        assert maxerr(d, fac_h.numpy()) <= 1e-4, s
