@@ -47,7 +47,7 @@ def reference_classes():
     return ns["PastEncoder"], ns["FutureEncoder"]
 
 
-def run(name, scales, B, seed, train=False):
+def run(name, scales, B, seed, train=False, nba=False):
     """train=True: the module in training mode, i.e. with the dropout of the positional encoder active
     (model/GroupNet_nba.py:195; mask drawn on the global CPU generator before the modules' uniforms)."""
     PastEncoder, _ = reference_classes()
@@ -61,8 +61,15 @@ def run(name, scales, B, seed, train=False):
             if "attention_mlp" in n or "MLP_distribution" in n or "MLP_factor" in n:
                 p.mul_(3.0)
     N, T = 11, 5
-    g = torch.Generator().manual_seed(seed + 1)
-    traj = torch.cumsum(torch.randn(B * N, T, 2, generator=g), dim=1) + torch.rand(B * N, 1, 2, generator=g) * 20
+    if nba:
+        # the 10 NBA scenes shipped with the reference, prepared as its loader and `GroupNet.inference` do:
+        # feet -> metres (data/dataloader_nba.py:36), (scene, agent, time, xy) (:49), the first past_length steps
+        a = np.load(os.path.join(REF, "datasets/nba/test_nba.npy")).astype(np.float32) / np.float32(94 / 28)
+        traj = torch.from_numpy(np.transpose(a, (0, 2, 1, 3))[:, :, :T, :].copy()).reshape(-1, T, 2)
+        B = a.shape[0]
+    else:
+        g = torch.Generator().manual_seed(seed + 1)
+        traj = torch.cumsum(torch.randn(B * N, T, 2, generator=g), dim=1) + torch.rand(B * N, 1, 2, generator=g) * 20
     vel = traj[:, 1:] - traj[:, :-1]
     x = torch.cat((traj, torch.cat([vel[:, [0]], vel], dim=1)), dim=-1)          # (B*N, T, 4), GroupNet_nba.py:792-797
     torch.manual_seed(seed + 2)
@@ -111,4 +118,5 @@ if __name__ == "__main__":
     run_future("noscale_b6", 6, 703)
     run("s5_11_b9", [5, 11], 9, 701)
     run("train_s5_11_b6", [5, 11], 6, 704, train=True)
+    run("nba_s5_11_b10", [5, 11], 10, 705, nba=True)      # BASELINE config 1's data: datasets/nba/test_nba.npy
     run("s2_5_11_b4", [2, 5, 11], 4, 702)

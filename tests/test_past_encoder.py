@@ -193,7 +193,7 @@ def _pe_golden(name):
     return c, sd
 
 
-@pytest.mark.parametrize("name", ["s5_11_b9", "s2_5_11_b4"])
+@pytest.mark.parametrize("name", ["s5_11_b9", "s2_5_11_b4", "nba_s5_11_b10"])
 def test_past_encoder_oracle_matches_reference_goldens(name):
     """The restatement (oracle/past_encoder_oracle.py + the pinned MS-HGNN oracle) reproduces what the
     REFERENCE's own `PastEncoder.forward` returned (its class definitions executed from /root/reference by the
@@ -208,10 +208,12 @@ def test_past_encoder_oracle_matches_reference_goldens(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["s5_11_b9", "s2_5_11_b4"])
+@pytest.mark.parametrize("name", ["s5_11_b9", "s2_5_11_b4", "nba_s5_11_b10"])
 def test_past_encoder_matches_reference_goldens(name):
     """The HIP `PastEncoder` with the reference's state_dict (strict load), the reference's inputs and the same
-    seeded host noise stream against the reference's own outputs."""
+    seeded host noise stream against the reference's own outputs.  `nba_s5_11_b10` = the 10 real NBA scenes the
+    reference ships (datasets/nba/test_nba.npy, BASELINE config 1's data), prepared as `GroupNet.inference`
+    prepares them, through the reference's own PastEncoder class."""
     from groupnet_amd.past_encoder import PastEncoder
     c, sd = _pe_golden(name)
     B, scales = int(c["B"]), [int(s) for s in c["scales"]]
