@@ -21,7 +21,6 @@ the same two blocks repeated, walked backwards.
 """
 from __future__ import annotations
 
-import ctypes
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
