@@ -81,7 +81,8 @@ def test_grouped_gemm_matches_torch():
     assert float((cs.double() - ref_cs).abs().max()) <= 1e-4 * float(ref_cs.abs().max())
 
 
-@pytest.mark.parametrize("B,N,scale,nmp", [(5, 11, 3, 1), (2, 7, 7, 1), (3, 20, 2, 1), (3, 11, 5, 2), (2, 6, 6, 3)])
+@pytest.mark.parametrize("B,N,scale,nmp", [(5, 11, 3, 1), (2, 7, 7, 1), (3, 20, 2, 1), (3, 11, 5, 2), (2, 6, 6, 3),
+                                           (2, 50, 8, 1), (2, 70, 16, 1)])      # config-4 shape; N > 64 (unfused gather)
 def test_hyper_module_gradients(B, N, scale, nmp):
     dev = torch.device("cuda:0")
     _, hyper = _modules(100 + N, nmp)
@@ -113,7 +114,7 @@ def test_hyper_module_gradients(B, N, scale, nmp):
     assert hip["spatial_embedding.weight"] is None and hip["edge_aggregation_list.0.mlp.layers.0.weight"] is None
 
 
-@pytest.mark.parametrize("B,N,nmp", [(4, 11, 1), (2, 5, 1), (2, 6, 2)])
+@pytest.mark.parametrize("B,N,nmp", [(4, 11, 1), (2, 5, 1), (2, 6, 2), (1, 50, 1)])      # last: config-4 shape, 1275 pair rows
 def test_pairwise_module_gradients(B, N, nmp):
     dev = torch.device("cuda:0")
     pair, _ = _modules(200 + N, nmp)
