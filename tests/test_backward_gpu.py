@@ -314,3 +314,29 @@ def test_graphed_train_step_with_adam():
                             seed=3, warmup=2)
     losses = [float(step(f, tgt)) for _ in range(12)]
     assert all(l == l for l in losses) and losses[-1] < losses[0]
+
+
+def test_pairwise_backward_beyond_the_per_scene_kernel():
+    """N = 150: the scene's rows no longer fit the per-scene node2edge backward, so the pairwise module's
+    backward falls back to ordered edge rows with the explicit (B, N*N, N) incidence, re-computes its edge-row
+    activations (the forward ran on unordered pairs) and uses the one-wave-per-hyperedge kernel with global
+    atomics.  Gradient of h and a sample of parameter gradients against the oracle's autograd."""
+    dev = torch.device("cuda:0")
+    B, N = 1, 150
+    pair, _ = _modules(321)
+    state = {k: v.detach().clone().requires_grad_(True) for k, v in pair.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    h = torch.randn(B, N, 64, generator=g)
+    U = [torch.rand(s, generator=g) for s in O.noise_shapes(B, N, None)]
+    R1 = torch.randn(B, N, 64, generator=g)
+    h_ref = h.clone().requires_grad_(True)
+    nf, fac = O.ms_hgnn_pairwise_forward(state, h_ref, U, decomposed=True)
+    (nf * R1).sum().backward()
+    pair.to(dev).train()
+    x = h.clone().to(dev).requires_grad_(True)
+    nf2, _ = pair(x, noise_u=[u.to(dev) for u in U])
+    assert float((nf2.detach().cpu() - nf.detach()).abs().max()) <= 1e-5
+    (nf2 * R1.to(dev)).sum().backward()
+    assert float((x.grad.cpu() - h_ref.grad).abs().max()) <= 2e-3 * float(h_ref.grad.abs().max())
+    used = [k for k, v in state.items() if v.grad is not None and float(v.grad.abs().max()) > 0]
+    _check({k: p.grad for k, p in pair.named_parameters()}, {k: v.grad for k, v in state.items()}, used)
