@@ -105,3 +105,40 @@ def sharded_forward(block: Callable[..., Tuple[Tensor, Optional[Tensor]]], f_ful
     if gather_H and H is not None:
         H = all_gather_rows(H, B, group)
     return feats_full, H
+
+
+def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None, average: bool = True,
+                        bucket_bytes: int = 256 << 20) -> None:
+    """Data-parallel training across the batch shards (SURVEY §8f rank 2 on more than one GPU): the one
+    exchange a training step adds is the sum of the parameter gradients.  They are flattened into as few
+    buckets as `bucket_bytes` allows (the whole MS-HGNN block is 4.3 MB: one bucket) and reduced with ONE
+    all-reduce each — xGMI rings are per-link bound, so few large messages — then scattered back in place.
+    A parameter without a gradient on this rank contributes zeros (every rank must issue identical collectives).
+    With `average` the sum is divided by the world size (the mean-over-batch loss of equal shards)."""
+    world = dist.get_world_size(group)
+    params = [p for p in params if p.requires_grad]
+    if world == 1 or not params:
+        return
+    buckets: List[List[torch.nn.Parameter]] = [[]]
+    size = 0
+    for p in params:
+        nbytes = p.numel() * p.element_size()
+        if buckets[-1] and size + nbytes > bucket_bytes:
+            buckets.append([])
+            size = 0
+        buckets[-1].append(p)
+        size += nbytes
+    for bucket in buckets:
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= world
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n

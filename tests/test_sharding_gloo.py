@@ -86,3 +86,41 @@ def test_shard_range_and_offsets():
     full = [torch.arange(8.0).view(8, 1, 1), [torch.arange(8.0).view(8, 1, 1)]]
     sl = sharding.slice_noise(full, 2, 5)
     assert sl[0].flatten().tolist() == [2, 3, 4] and sl[1][0].flatten().tolist() == [2, 3, 4]
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(5)
+        params = [torch.nn.Parameter(torch.randn(s)) for s in [(3, 4), (7,), (2, 2, 2), (5,)]]
+        params[3].requires_grad_(False)
+        g = torch.Generator().manual_seed(100 + rank)
+        for i, p in enumerate(params[:3]):
+            if not (rank == 1 and i == 1):          # rank 1 has no gradient for parameter 1
+                p.grad = torch.randn(p.shape, generator=g)
+        sharding.allreduce_gradients(params, average=True, bucket_bytes=64)      # tiny buckets: several collectives
+        torch.save([None if p.grad is None else p.grad.clone() for p in params], os.path.join(out_dir, f"g{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_gradients_buckets_and_missing_grads(tmp_path):
+    world = 2
+    mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"g{r}.pt")) for r in range(world)]
+    # expected: mean over ranks of the per-rank gradients (zeros where a rank had none)
+    want = []
+    for i, shape in enumerate([(3, 4), (7,), (2, 2, 2)]):
+        acc = torch.zeros(shape)
+        for r in range(world):
+            g = torch.Generator().manual_seed(100 + r)
+            gs = [torch.randn(s, generator=g) if not (r == 1 and j == 1) else None for j, s in enumerate([(3, 4), (7,), (2, 2, 2)])]
+            if gs[i] is not None:
+                acc += gs[i]
+        want.append(acc / world)
+    for r in range(world):
+        for i in range(3):
+            assert torch.allclose(got[r][i], want[i], atol=1e-6), (r, i)
+        assert got[r][3] is None        # frozen parameter untouched
