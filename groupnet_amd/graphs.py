@@ -72,6 +72,56 @@ class GraphedMultiScale:
         return self.out, self.H
 
 
+class GraphedPastEncoder:
+    """Static-shape, replayable inference forward of a `PastEncoder` drop-in (embedding front-end, affinity,
+    incidences, all modules, concat — `model/GroupNet_nba.py:266-315`) as one hipGraph.
+
+        g = GraphedPastEncoder(enc.eval(), B, N, seed=7)
+        feats, new_H = g(inputs)       # inputs (B*N, T, in_dim) copied into the static buffer; outputs static
+    """
+
+    def __init__(self, enc, B: int, N: int, seed: int = 0, warmup: int = 2):
+        p = next(enc.parameters())
+        self.device = p.device
+        if self.device.type != "cuda":
+            raise ValueError("GraphedPastEncoder needs the encoder on a GPU")
+        if enc.training:
+            raise ValueError("GraphedPastEncoder captures the inference path: call enc.eval() first")
+        self.enc, self.B, self.N, self.seed = enc, B, N, int(seed)
+        self.x_in = torch.zeros((B * N, enc._length, enc.input_fc.in_features), dtype=torch.float32, device=self.device)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        E = [1 if m.scale == N else N for m in (getattr(enc, n) for n in enc._hyper_names)]
+        self.draws_per_step = B * N * N * enc.interaction.edge_types + sum(B * e * 10 for e in E)
+        self.graph = torch.cuda.CUDAGraph()
+        prev = (_mods._NoiseState.mode, _mods._NoiseState.seed, _mods._NoiseState.offset, _mods._NoiseState.counter)
+        try:
+            with torch.no_grad(), torch.cuda.device(self.device):
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    for _ in range(max(1, warmup)):
+                        self._step()
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                torch.cuda.synchronize(self.device)
+                self.counter.fill_(-self.draws_per_step)
+                with torch.cuda.graph(self.graph):
+                    self.out, self.H = self._step()
+        finally:
+            enc.__dict__.pop("_advance", None)
+            _mods.set_noise_mode(prev[0], prev[1], prev[2], prev[3])
+
+    def _step(self):
+        _mods.set_noise_mode("device", seed=self.seed, offset=0, counter=self.counter)
+        self.enc._advance = (self.counter, self.draws_per_step)
+        return self.enc(self.x_in, self.B, self.N)
+
+    def __call__(self, inputs: Optional[Tensor] = None):
+        if inputs is not None:
+            self.x_in.copy_(inputs, non_blocking=True)
+        self.graph.replay()
+        return self.out, self.H
+
+
 class GraphedTrainStep:
     """One training step of a ``MultiScaleHGNN`` block — forward, loss, backward and the optimizer update —
     captured in ONE hipGraph (`train_hyper_nba.py:107-118` is this loop).

@@ -170,8 +170,11 @@ class _TrajectoryEncoder(nn.Module):
         x_raw = inputs.reshape(B, N, T * inputs.shape[2])
         final = torch.empty((B, N, D * (2 + S)), dtype=inputs.dtype, device=inputs.device)
         cols = [final[..., D * (1 + i):D * (2 + i)] for i in range(1 + S)]
+        adv = self.__dict__.get("_advance")      # (device counter, draws per call): set by graphs.GraphedPastEncoder
         _, Hs, new_H, f = ops.affinity_topk(None, scales or [N], want_corr=False, f_out=final[..., :D],
-                                            want_H_cat=S > 1, embed=(x_raw, M, c))    # >= 1 scale per launch; N = the
+                                            want_H_cat=S > 1, embed=(x_raw, M, c),
+                                            counter=adv[0] if adv else None,
+                                            counter_add=adv[1] if adv else 0)        # >= 1 scale per launch; N = the
         if S == 0:                                                                     # cheap all-ones edge
             Hs, new_H = [], None
         elif S == 1:

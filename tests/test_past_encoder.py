@@ -284,3 +284,30 @@ def test_past_encoder_training_mode_matches_reference_golden():
     want = torch.from_numpy(c["output_feature"])
     assert float((out.detach().cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
     assert torch.equal(new_H.cpu(), torch.from_numpy(c["new_H"]))
+
+
+@pytest.mark.gpu
+def test_graphed_past_encoder_replays_eager_with_fresh_noise():
+    """One hipGraph for the whole encoder: replay k equals an eager forward at Philox position k * draws, and
+    consecutive replays draw different noise."""
+    import groupnet_amd as G
+    from groupnet_amd.graphs import GraphedPastEncoder
+    enc = make([5, 11], seed=2)
+    dev = torch.device("cuda:0")
+    enc.to(dev)
+    B, N = 16, 11
+    x = _inputs(B, N, 5, torch.Generator().manual_seed(3)).to(dev)
+    g = GraphedPastEncoder(enc, B, N, seed=21)
+    out0, H0 = [t.clone() for t in g(x)]
+    out1, _ = [t.clone() for t in g()]
+    assert float((out0[:, 64:] - out1[:, 64:]).abs().max()) > 0          # fresh Gumbel noise
+    assert torch.equal(out0[:, :64], out1[:, :64])                        # the embedding itself is noise-free
+    for k, want in ((0, out0), (1, out1)):
+        counter = torch.full((1,), k * g.draws_per_step, dtype=torch.int64, device=dev)
+        G.set_noise_mode("device", seed=21, offset=0, counter=counter)
+        try:
+            with torch.no_grad():
+                eager, H = enc(x, B, N)
+        finally:
+            G.set_noise_mode("host")
+        assert torch.equal(eager, want) and torch.equal(H, H0)
