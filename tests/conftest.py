@@ -15,6 +15,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The shared objects are build artefacts (git-ignored): on a fresh checkout build them before collection,
+    # exactly as __graft_entry__.build() does (hipcc cross-compiles without a GPU).
+    lib = os.path.join(ROOT, "groupnet_amd", "libgroupnet_hip.so")
+    topk = os.path.join(ROOT, "oracle", "_build", "liboracle_topk.so")
+    if not (os.path.exists(lib) and os.path.exists(topk)):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "groupnet_amd", "csrc")], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
 
 
 def pytest_collection_modifyitems(config, items):
