@@ -340,3 +340,42 @@ def test_pairwise_backward_beyond_the_per_scene_kernel():
     assert float((x.grad.cpu() - h_ref.grad).abs().max()) <= 2e-3 * float(h_ref.grad.abs().max())
     used = [k for k, v in state.items() if v.grad is not None and float(v.grad.abs().max()) > 0]
     _check({k: p.grad for k, p in pair.named_parameters()}, {k: v.grad for k, v in state.items()}, used)
+
+
+def test_results_do_not_depend_on_stale_memory():
+    """Every buffer of the forward and the backward comes from torch.empty / a zeroed pool; poisoning the caching
+    allocator's free blocks with NaN between two identical steps must change nothing (beyond the order of
+    atomic additions in the weight gradients)."""
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+
+    def poison():
+        junk = [torch.full((n,), float("nan"), device=dev) for n in (1 << k for k in range(8, 25))]
+        junk += [torch.full((3 * n,), float("nan"), device=dev) for n in (1 << k for k in range(8, 23))]
+        del junk
+
+    for B, N, scales in ((37, 11, [2, 5, 11]), (3, 50, [4, 50])):
+        blk = MultiScaleHGNN(scales).to(dev).train()
+        f = torch.randn(B, N, 64, device=dev)
+        noise = [[torch.rand(s, device=dev)] for s in blk.noise_shapes(B, N)]
+        R = torch.randn(B, N, blk.out_features, device=dev)
+
+        def run():
+            for p in blk.parameters():
+                p.grad = None
+            x = f.clone().requires_grad_(True)
+            out, _ = blk(x, noise_u=noise)
+            (out * R).sum().backward()
+            return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in blk.parameters() if p.grad is not None]
+
+        o1, g1, w1 = run()
+        torch.cuda.synchronize()
+        poison()
+        torch.cuda.synchronize()
+        o2, g2, w2 = run()
+        assert torch.equal(o1, o2)
+        assert float((g1 - g2).abs().max()) <= 1e-5 * float(g1.abs().max())
+        for a, b in zip(w1, w2):
+            assert bool(torch.isfinite(b).all())
+            assert float((a - b).abs().max()) <= 1e-4 * (float(a.abs().max()) + 1e-6)
