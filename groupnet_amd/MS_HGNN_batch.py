@@ -283,11 +283,13 @@ class edge_aggregation(nn.Module):
             self._plan = (tuple(p.data_ptr() for p in params), plan)
             self._pk = dict(W=plan.view(w0, w_len), b1=plan.view(b1o, K * 128).view(K, 128),
                             b2=plan.view(b2o, K * 64).view(K, 64), W1cat=plan.view(w1c, K * 8 * T),
-                            b1half=plan.view(bho, K * 128), W2t=plan.view(w2t, K * 8 * T))
+                            b1half=plan.view(bho, K * 128), W2t=plan.view(w2t, K * 8 * T),
+                            W2x3=torch.empty(K * 8 * 2 * 3 * 64 * 8, dtype=torch.int16, device=params[0].device))
             self._pk_key = None
         key = _param_key(params)
         if key != self._pk_key:
             self._plan[1].refresh()
+            ops.split_bf16x3(self._pk["W2t"], self._pk["W2x3"])     # layer 2 as three bf16 parts (pair form)
             self._pk_key = key
         return self._pk
 

@@ -72,6 +72,31 @@ __global__ __launch_bounds__(256) void pack_segments_kernel(const gn_pack_seg_t*
   }
 }
 
+// fp32 -> three bf16 parts (round to nearest even each time; the remainders are exact in fp32)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
+  p1 = (__bf16)x;
+  const float r1 = x - (float)p1;
+  p2 = (__bf16)r1;
+  p3 = (__bf16)(r1 - (float)p2);
+}
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ packed, __bf16* __restrict__ out,
+                                                           int n_tiles) {
+  // one thread per (tile, half, lane, j)
+  const long long total = (long long)n_tiles * 2 * 64 * 8;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63), half = (int)((idx >> 9) & 1);
+    const long long tile = idx >> 10;
+    const float x = packed[tile * kTileFloats + (((j >> 2) + 2 * half) * 64 + lane) * 4 + (j & 3)];
+    __bf16 p1, p2, p3;
+    split3(x, p1, p2, p3);
+    __bf16* o = out + ((tile * 2 + half) * 3 * 64 + lane) * 8 + j;
+    o[0] = p1;
+    o[64 * 8] = p2;
+    o[2 * 64 * 8] = p3;
+  }
+}
+
 // ---- register-resident building blocks -----------------------------------------------------
 template <int IT>
 __device__ __forceinline__ void load_rows(const float* __restrict__ X, int ld, int row, int h, f32x16 (&a)[IT]) {
@@ -586,7 +611,130 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
   const float* b2 = G.b2;
 
   int k = sub;
-  if (G.A != nullptr && staged) {
+  if (G.A != nullptr && staged && G.W2x3 != nullptr) {
+    // ---- pair form, staged: every lane needs the pre-activations of ITS two nodes — 16-byte pieces scattered
+    // over up to 32 rows per load, which makes the texture-address path, not the matrix cores, the limiter.
+    // The 4 row blocks of this workgroup touch at most 3 scenes, i.e. a short run of consecutive node rows: the
+    // workgroup copies that run (one type at a time, coalesced, prefetched in registers under the previous
+    // type's MFMAs) into LDS, and the lanes pick their rows from there.
+    float* stage = &part[0][0][0];
+    const int N = G.N, P = G.E;
+    const int r0 = wg * 128, r1 = min(rows - 1, r0 + 127);
+    const int node0 = (r0 / P) * N;
+    const int nodes = (r1 / P + 1) * N - node0;
+    const size_t ldA = (size_t)K * 128;
+    const f32x4* Ag = reinterpret_cast<const f32x4*>(G.A + (size_t)node0 * ldA);
+    const int total4 = nodes * 32;                      // float4 pieces per type
+    f32x4 pre[kStageLoads];
+    auto fetch = [&](int kk) {
+#pragma unroll
+      for (int it = 0; it < kStageLoads; ++it) {
+        const int idx = min((int)threadIdx.x + it * 256, total4 - 1);
+        pre[it] = Ag[(size_t)(idx >> 5) * (ldA / 4) + kk * 32 + (idx & 31)];
+      }
+    };
+    auto commit = [&]() {
+#pragma unroll
+      for (int it = 0; it < kStageLoads; ++it) {
+        const int idx = (int)threadIdx.x + it * 256;
+        if (idx < total4) *reinterpret_cast<f32x4*>(stage + (idx >> 5) * kStagePitch + (idx & 31) * 4) = pre[it];
+      }
+    };
+    int i = 0, j = 0;
+    {
+      const int b = rb.row_ld / P, p = rb.row_ld - b * P;
+      gn_pair_decode(p, N, i, j);
+      i += b * N - node0;
+      j += b * N - node0;
+    }
+    const float* Si = stage + i * kStagePitch;
+    const float* Sj = stage + j * kStagePitch;
+    // bf16x6 route: this lane's pointer into the three-part image; tile (k,t,o), half hf, part p sits at
+    // ((((k*8 + t*2 + o)*2 + hf)*3 + p)*64 + lane) 16-byte pieces
+    const f32x4* Wx = reinterpret_cast<const f32x4*>(G.W2x3) + lane;
+    f32x4 wq[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) wq[u] = Wx[u * 64];
+    fetch(0);
+    commit();
+    __syncthreads();
+    PreTile pa = load_pre(Si, h), pb = load_pre(Sj, h);
+    float efk = efrow[0];
+    float b2f0 = h == 0 ? b2[lane & 31] : 0.f;
+    float b2f1 = h == 0 ? b2[32 + (lane & 31)] : 0.f;
+#pragma unroll 1
+    for (k = 0; k < K; ++k) {
+      const int kc = k + 1 < K ? k + 1 : k;
+      fetch(kc);                                        // next type's rows: in flight during this type's MFMAs
+      const float efk_next = efrow[kc];
+      const float b2n0 = h == 0 ? b2[kc * 64 + (lane & 31)] : 0.f;
+      const float b2n1 = h == 0 ? b2[kc * 64 + 32 + (lane & 31)] : 0.f;
+      const float efb = h == 0 ? efk : 0.f;
+      out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f0, efb, out[0], 0, 0, 0);
+      out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f1, efb, out[1], 0, 0, 0);
+      {
+        // ---- fp32-accurate products on the bf16 cores: x = x1 + x2 + x3 (bf16 parts), weights pre-split;
+        //      w.x ~ w3x1 + w2x2 + w1x3 + w2x1 + w1x2 + w1x1 (small terms first), six k=16 MFMAs per half tile.
+        //      Weight parts of tile (k, t, o), half hf: 3 x 16 bytes per lane, fetched one hidden tile ahead.
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f32x16 hid1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx)
+              hid1[4 * q + cidx] = fmaxf(pa.v[q][cidx] + pb.v[q][cidx], 0.f) * efk;
+          if (t < 3) {
+            pa = load_pre(Si + 32 * (t + 1), h);
+            pb = load_pre(Sj + 32 * (t + 1), h);
+          }
+          // wq holds this hidden tile's 4 x 3 weight pieces; each triple is refilled with the NEXT tile's right
+          // after its six MFMAs are issued (24 MFMAs of run-ahead)
+          const int tn = t < 3 ? t + 1 : 0, kn = t < 3 ? k : kc;
+          const f32x4* src = Wx + ((size_t)(kn * 8 + tn * 2) * 6) * 64;
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            bf16x8 x1, x2, x3;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+              __bf16 a, b, c;
+              split3(hid1[8 * hf + jj], a, b, c);
+              x1[jj] = a;
+              x2[jj] = b;
+              x3[jj] = c;
+            }
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+              const int u = (o * 2 + hf) * 3;
+              const bf16x8 w1 = __builtin_bit_cast(bf16x8, wq[u + 0]);
+              const bf16x8 w2 = __builtin_bit_cast(bf16x8, wq[u + 1]);
+              const bf16x8 w3 = __builtin_bit_cast(bf16x8, wq[u + 2]);
+              f32x16& acc = out[o];
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x3, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x1, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x2, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc, 0, 0, 0);
+              wq[u + 0] = src[(u + 0) * 64];
+              wq[u + 1] = src[(u + 1) * 64];
+              wq[u + 2] = src[(u + 2) * 64];
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      }
+      __syncthreads();                                  // every wave has read type k's rows
+      commit();
+      __syncthreads();
+      pa = load_pre(Si, h);
+      pb = load_pre(Sj, h);
+      efk = efk_next;
+      b2f0 = b2n0;
+      b2f1 = b2n1;
+    }
+    if (!any_rows) return;
+  } else if (G.A != nullptr && staged) {
     // ---- pair form, staged: every lane needs the pre-activations of ITS two nodes — 16-byte pieces scattered
     // over up to 32 rows per load, which makes the texture-address path, not the matrix cores, the limiter.
     // The 4 row blocks of this workgroup touch at most 3 scenes, i.e. a short run of consecutive node rows: the
@@ -1070,6 +1218,17 @@ extern "C" int gn_pack_linear_f32(const float* W, float* Wp, int out_features, i
   const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
   hipLaunchKernelGGL(pack_linear_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, Wp, out_features,
                      in_features, ld, col_offset, OT, IT);
+  return gn_check_launch();
+}
+
+extern "C" int gn_split_bf16x3_f32(const float* packed, void* out, int n_tiles, gn_stream_t stream) {
+  GN_REQUIRE_PTR(packed);
+  GN_REQUIRE_PTR(out);
+  if (n_tiles < 1) return GN_ERR_SHAPE;
+  GN_REQUIRE_ALIGNED(out);
+  const long long total = (long long)n_tiles * 1024;
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)),
+                     dim3(256), 0, (hipStream_t)stream, packed, reinterpret_cast<__bf16*>(out), n_tiles);
   return gn_check_launch();
 }
 

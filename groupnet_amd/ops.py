@@ -8,6 +8,7 @@ CPU oracle or falls back to torch math.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -527,6 +528,21 @@ class PairSpec:
         self.A = A
 
 
+BF16X6 = os.environ.get("GN_AGG_BF16X6", "1") != "0"   # pair form: fp32-accurate products on the bf16 cores
+
+
+def split_bf16x3(packed: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """Three-bf16-part image (16-bit words, as int16) of packed fp32 32x32 weight tiles: `gn_split_bf16x3_f32`."""
+    _req(packed, "packed")
+    n_tiles = packed.numel() // 1024
+    if out is None:
+        out = torch.empty(n_tiles * 2 * 3 * 64 * 8, dtype=torch.int16, device=packed.device)
+    with torch.cuda.device(packed.device):
+        check(load().gn_split_bf16x3_f32(_ptr(packed), ctypes.c_void_p(out.data_ptr()), n_tiles, stream_handle()),
+              "gn_split_bf16x3_f32")
+    return out
+
+
 def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[Tensor]:
     """items = [(eo (B,E,64) | GatherSpec | PairSpec, edge_feat (B,E,K), pk{"W","b1","b2"[,"W2t"]}, K)]
     -> [feat (B,E,64)]."""
@@ -544,7 +560,8 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
             E = pair_count(N)
             _same_device(A, edge_feat)
             like, eo_ptr, wkey = A, 0, "W2t"
-            extra = (0, 0, E, N, 1, A.data_ptr())
+            w3 = pk.get("W2x3") if BF16X6 else None
+            extra = (0, 0, E, N, 1, A.data_ptr(), 0 if w3 is None else w3.data_ptr())
         elif isinstance(eo, GatherSpec):
             ori, H = eo.ori, eo.H
             _req(ori, "ori", (None, None, FEAT))
@@ -552,13 +569,13 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
             E = _edge_count(H, B, N, eo.sym)
             _same_device(ori, H, edge_feat)
             like, eo_ptr = ori, 0
-            extra = (ori.data_ptr(), 0 if H is None else H.data_ptr(), E, N, int(eo.sym), 0)
+            extra = (ori.data_ptr(), 0 if H is None else H.data_ptr(), E, N, int(eo.sym), 0, 0)
         else:
             _req(eo, "eo", (None, None, FEAT))
             B, E, _ = eo.shape
             _same_device(eo, edge_feat)
             like, eo_ptr = eo, eo.data_ptr()
-            extra = (0, 0, 0, 0, 0, 0)
+            extra = (0, 0, 0, 0, 0, 0, 0)
         dev0 = dev0 or like.device
         if like.device != dev0:
             raise ValueError("grouped launch: every group must be on the same device")

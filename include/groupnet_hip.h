@@ -259,8 +259,18 @@ typedef struct {
   int N;
   int sym;
   const float* A;
+  const void* W2x3;   /* optional, pair form: layer 2 of every type as three bf16 parts in the 32x32x16 operand
+                         order (gn_split_bf16x3_f32 of the W image).  When present the pair form forms its
+                         products from the six significant bf16 part-products — as accurate as fp32
+                         accumulation, twice the matrix rate */
 } gn_agg_group_t;
 int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream);
+/* Packed fp32 32x32 weight tiles (gn_pack_linear_f32 layout, n_tiles of 1024 floats) -> for every tile and
+ * each of its two k-halves three bf16 parts (x = p1 + p2 + p3, 8 mantissa bits each) in the A-operand order
+ * of v_mfma_f32_32x32x16_bf16: out[(((tile*2 + half)*3 + part)*64 + lane)*8 + j] (16-bit words), where
+ * element j of lane (m, h) is the weight of output m and k-feature 16*half + (j&3) + 8*(j>>2) + 4*h — the
+ * order in which a lane's accumulator registers hold those features. */
+int gn_split_bf16x3_f32(const float* packed, void* out, int n_tiles, gn_stream_t stream);
 
 /* ---- A5, pairwise graph, layer 1 hoisted to the nodes -----------------------------------------
  * For the pairwise graph the typed MLP's input row is eo = ori_i + ori_j, so its first layer is

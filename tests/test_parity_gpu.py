@@ -914,3 +914,30 @@ def test_modules_under_extreme_magnitudes(in_scale, w_scale):
         assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(d).all())
         assert maxerr(c, nf_h.numpy()) <= 2e-5 * max(1.0, float(nf_h.abs().max())), s
         assert maxerr(d, fac_h.numpy()) <= 1e-4, s
+
+
+def test_pair_form_on_the_bf16_cores_is_fp32_accurate():
+    """The pair form of the typed aggregation at a size where its workgroups stage node rows in LDS (B=512)
+    forms layer 2 from bf16 part-products (x = x1+x2+x3, six products): against the fp32-MFMA pair form
+    (`ops.BF16X6 = False`) and against the ordered-edge oracle-checked form — fp32 accuracy, not bf16's."""
+    from groupnet_amd import ops
+    torch.manual_seed(31)
+    pair, _ = build_modules(1)
+    pair.to(dev())
+    B, N, K = 512, 11, 6
+    ori = torch.randn(B, N, 64, device=dev()) * 2.0
+    ef = torch.rand(B, ops.pair_count(N), K, device=dev())
+    pk = pair.edge_aggregation_list[0]._packed()
+    A = ops.node_linear(ori, pk["W1cat"], pk["b1half"], K * 128)
+    assert ops.BF16X6
+    got = ops.agg_mlp_grouped([(ops.PairSpec(A), ef, pk, K)])[0]
+    ops.BF16X6 = False
+    try:
+        ref = ops.agg_mlp_grouped([(ops.PairSpec(A), ef, pk, K)])[0]
+    finally:
+        ops.BF16X6 = True
+    eo = ops.agg_gather(ori, None, sym=True)
+    plain = ops.agg_mlp(eo, ef, pk, K)                 # both layers on the fp32 matrix cores, explicit eo
+    scale = float(plain.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-6 * scale
+    assert float((got - plain).abs().max()) <= 4e-6 * scale
