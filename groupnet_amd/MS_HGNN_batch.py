@@ -270,8 +270,13 @@ class edge_aggregation(nn.Module):
                 plan.matrix(b.weight)
             w_len = plan.size - w0
             b1o, b2o, bho = plan.alloc(K * 128), plan.alloc(K * 64), plan.alloc(K * 128)
-            w1c, w2t = plan.alloc(K * 8 * T), plan.alloc(K * 8 * T)
+            w1c, w2t, w12 = plan.alloc(K * 8 * T), plan.alloc(K * 8 * T), plan.alloc(K * 16 * T)
             for k in range(K):
+                for o in range(4):      # hidden-tile-major image of both layers (source of the bf16x3 image)
+                    base = w12 + (k * 16 + o * 4) * T
+                    plan.block(base, l0[k].weight, 2, r0=32 * o, rows=32)
+                    plan.block(base + 2 * T, l1[k].weight, 1, r0=0, c0=32 * o, rows=32, cols=32)
+                    plan.block(base + 3 * T, l1[k].weight, 1, r0=32, c0=32 * o, rows=32, cols=32)
                 plan.vector(b1o + 128 * k, l0[k].bias)
                 plan.vector(b2o + 64 * k, l1[k].bias)
                 plan.vector(bho + 128 * k, l0[k].bias, scale=0.5)
@@ -284,12 +289,15 @@ class edge_aggregation(nn.Module):
             self._pk = dict(W=plan.view(w0, w_len), b1=plan.view(b1o, K * 128).view(K, 128),
                             b2=plan.view(b2o, K * 64).view(K, 64), W1cat=plan.view(w1c, K * 8 * T),
                             b1half=plan.view(bho, K * 128), W2t=plan.view(w2t, K * 8 * T),
-                            W2x3=torch.empty(K * 8 * 2 * 3 * 64 * 8, dtype=torch.int16, device=params[0].device))
+                            W2x3=torch.empty(K * 8 * 2 * 3 * 64 * 8, dtype=torch.int16, device=params[0].device),
+                            W12=plan.view(w12, K * 16 * T),
+                            W12x3=torch.empty(K * 16 * 2 * 3 * 64 * 8, dtype=torch.int16, device=params[0].device))
             self._pk_key = None
         key = _param_key(params)
         if key != self._pk_key:
             self._plan[1].refresh()
             ops.split_bf16x3(self._pk["W2t"], self._pk["W2x3"])     # layer 2 as three bf16 parts (pair form)
+            ops.split_bf16x3(self._pk["W12"], self._pk["W12x3"])    # both layers, hidden-tile-major (two-layer form)
             self._pk_key = key
         return self._pk
 

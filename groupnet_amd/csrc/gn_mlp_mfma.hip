@@ -585,7 +585,7 @@ __device__ __forceinline__ void relu_scale16(f32x16& a, float w) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f) * w;
 }
-__global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
+__global__ __launch_bounds__(256, 2) void agg_mlp_kernel(GroupTable<AggGroup> T) {
   __shared__ float part[4][32][64];  // wpr > 1 only: [wave][register 0..31][lane]
   const int gi = find_group(T, blockIdx.x);
   const gn_agg_group_t G = T.g[gi].a;
@@ -877,6 +877,98 @@ __global__ __launch_bounds__(256) void agg_mlp_kernel(GroupTable<AggGroup> T) {
         b2f1 = b2n1;
         k = kn;
       }
+    }
+  } else if (G.W12x3 != nullptr && k < K && any_rows) {
+    // ---- two-layer form with fp32-accurate products on the bf16 cores.  Hidden-tile by hidden-tile: tile o of
+    // layer 1 (4 sub-steps: in tile t, half hf), ReLU * ef_k, its three bf16 parts, then its contribution to
+    // both output tiles (4 sub-steps) — only one hidden tile is ever live.  A sub-step = three 16-byte weight
+    // pieces per lane and six MFMAs; the pieces run through a 4-sub-step ring refilled in place (24 MFMAs ahead),
+    // in exactly the order gn_split_bf16x3_f32 of the hidden-tile-major image lays them out.
+    f32x16 in[2];
+    if (G.eo != nullptr)
+      load_rows<2>(G.eo, GN_FEAT, rb.row_ld, h, in);
+    else
+      gather_rows(G, rb.row_ld, h, in);
+    bf16x8 xin[2][2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          __bf16 a, b, c;
+          split3(in[t][8 * hf + jj], a, b, c);
+          xin[t][hf][0][jj] = a;
+          xin[t][hf][1][jj] = b;
+          xin[t][hf][2][jj] = c;
+        }
+    const f32x4* Wx = reinterpret_cast<const f32x4*>(G.W12x3) + lane;   // sub-step s of type k: ((k*32 + s)*3 + part)*64
+    f32x4 wq[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) wq[u] = Wx[((size_t)k * 32 * 3 + u) * 64];
+    f32x16 bnext = load_bias_tile(b1 + k * 128, h);
+    float efk = efrow[k];
+    float b2f0 = h == 0 ? b2[k * 64 + (lane & 31)] : 0.f;
+    float b2f1 = h == 0 ? b2[k * 64 + 32 + (lane & 31)] : 0.f;
+#pragma unroll 1
+    while (k < K) {
+      const int kn = k + wpr;
+      const int kc = kn < K ? kn : k;
+      const f32x4* cur = Wx + (size_t)k * 32 * 3 * 64;
+      const f32x4* nxt = Wx + (size_t)kc * 32 * 3 * 64;
+      const float efk_next = efrow[kc];
+      const float b2n0 = h == 0 ? b2[kc * 64 + (lane & 31)] : 0.f;
+      const float b2n1 = h == 0 ? b2[kc * 64 + 32 + (lane & 31)] : 0.f;
+      const float efb = h == 0 ? efk : 0.f;
+      out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f0, efb, out[0], 0, 0, 0);
+      out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f1, efb, out[1], 0, 0, 0);
+      // one sub-step: six part-products into acc, then refill the ring slot with the sub-step 4 ahead
+      auto sub = [&](int s, const bf16x8 (&x)[3], f32x16& acc) {
+        const int u = (s & 3) * 3;
+        const bf16x8 w1 = __builtin_bit_cast(bf16x8, wq[u + 0]);
+        const bf16x8 w2 = __builtin_bit_cast(bf16x8, wq[u + 1]);
+        const bf16x8 w3 = __builtin_bit_cast(bf16x8, wq[u + 2]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x[0], acc, 0, 0, 0);
+        const f32x4* src = s + 4 < 32 ? cur + (size_t)(s + 4) * 3 * 64 : nxt + (size_t)(s + 4 - 32) * 3 * 64;
+        wq[u + 0] = src[0];
+        wq[u + 1] = src[64];
+        wq[u + 2] = src[128];
+        __builtin_amdgcn_sched_barrier(0);
+      };
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        f32x16 hid = bnext;
+        bnext = load_bias_tile(o < 3 ? b1 + k * 128 + 32 * (o + 1) : b1 + kc * 128, h);
+        sub(8 * o + 0, xin[0][0], hid);
+        sub(8 * o + 1, xin[0][1], hid);
+        sub(8 * o + 2, xin[1][0], hid);
+        sub(8 * o + 3, xin[1][1], hid);
+        relu_scale16(hid, efk);
+        bf16x8 xh[2][3];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            __bf16 a, b, c;
+            split3(hid[8 * hf + jj], a, b, c);
+            xh[hf][0][jj] = a;
+            xh[hf][1][jj] = b;
+            xh[hf][2][jj] = c;
+          }
+        sub(8 * o + 4, xh[0], out[0]);
+        sub(8 * o + 5, xh[1], out[0]);
+        sub(8 * o + 6, xh[0], out[1]);
+        sub(8 * o + 7, xh[1], out[1]);
+      }
+      efk = efk_next;
+      b2f0 = b2n0;
+      b2f1 = b2n1;
+      k = kn;
     }
   } else if (k < K && any_rows) {
     f32x16 in[2], hid[4];

@@ -561,7 +561,7 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
             _same_device(A, edge_feat)
             like, eo_ptr, wkey = A, 0, "W2t"
             w3 = pk.get("W2x3") if BF16X6 else None
-            extra = (0, 0, E, N, 1, A.data_ptr(), 0 if w3 is None else w3.data_ptr())
+            extra = (0, 0, E, N, 1, A.data_ptr(), 0 if w3 is None else w3.data_ptr(), 0)
         elif isinstance(eo, GatherSpec):
             ori, H = eo.ori, eo.H
             _req(ori, "ori", (None, None, FEAT))
@@ -569,13 +569,16 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
             E = _edge_count(H, B, N, eo.sym)
             _same_device(ori, H, edge_feat)
             like, eo_ptr = ori, 0
-            extra = (ori.data_ptr(), 0 if H is None else H.data_ptr(), E, N, int(eo.sym), 0, 0)
+            w12 = pk.get("W12x3") if BF16X6 else None
+            extra = (ori.data_ptr(), 0 if H is None else H.data_ptr(), E, N, int(eo.sym), 0, 0,
+                     0 if w12 is None else w12.data_ptr())
         else:
             _req(eo, "eo", (None, None, FEAT))
             B, E, _ = eo.shape
             _same_device(eo, edge_feat)
             like, eo_ptr = eo, eo.data_ptr()
-            extra = (0, 0, 0, 0, 0, 0, 0)
+            w12 = pk.get("W12x3") if BF16X6 else None
+            extra = (0, 0, 0, 0, 0, 0, 0, 0 if w12 is None else w12.data_ptr())
         dev0 = dev0 or like.device
         if like.device != dev0:
             raise ValueError("grouped launch: every group must be on the same device")

@@ -263,6 +263,9 @@ typedef struct {
                          order (gn_split_bf16x3_f32 of the W image).  When present the pair form forms its
                          products from the six significant bf16 part-products — as accurate as fp32
                          accumulation, twice the matrix rate */
+  const void* W12x3;  /* optional, two-layer form: the same for both layers, hidden-tile-major: per type and
+                         hidden tile o the tiles [W1k(o, in 0), W1k(o, in 1), W2k(out 0, o), W2k(out 1, o)]
+                         (gn_split_bf16x3_f32 of that fp32 stream) */
 } gn_agg_group_t;
 int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream);
 /* Packed fp32 32x32 weight tiles (gn_pack_linear_f32 layout, n_tiles of 1024 floats) -> for every tile and
