@@ -209,6 +209,20 @@ class MLP_dict_softmax(nn.Module):
                     b0(t + 2)
             plan.alloc(2 * T)
             w_len = plan.size - w0
+            # hidden-tile-major stream of the same four layers (source of the three-bf16-part image): 40 tiles
+            wh = plan.alloc(40 * T)
+            for t in range(4):
+                base = wh + 4 * t * T
+                plan.block(base, i0.weight, 2, r0=32 * t, rows=32)
+                plan.block(base + 2 * T, i1.weight, 1, r0=0, c0=32 * t, rows=32, cols=32)
+                plan.block(base + 3 * T, i1.weight, 1, r0=32, c0=32 * t, rows=32, cols=32)
+            for t in range(8):
+                base = wh + (16 + 3 * t) * T
+                plan.block(base, (d0 if t < 4 else f0).weight, 2, r0=32 * (t % 4), rows=32)
+                if t < 4:
+                    plan.block(base + 2 * T, d1.weight, 1, c0=32 * t, cols=32)
+                else:
+                    plan.block(base + 2 * T, f1.weight, 1, c0=32 * (t - 4), cols=32, place_r=K)
             bo = plan.alloc(128 + 64 + 256 + 32)
             plan.vector(bo, i0.bias)
             plan.vector(bo + 128, i1.bias)
@@ -218,11 +232,13 @@ class MLP_dict_softmax(nn.Module):
             plan.vector(bo + 448, f1.bias, place=K)
             plan.finish()
             self._plan = (plan.sources[:0] + tuple(p.data_ptr() for p in params), plan)
-            self._pk = dict(W=plan.view(w0, w_len), bias=plan.view(bo, 480))
+            self._pk = dict(W=plan.view(w0, w_len), bias=plan.view(bo, 480), Wh=plan.view(wh, 40 * T),
+                            Wx3=torch.empty(40 * 2 * 3 * 64 * 8, dtype=torch.int16, device=params[0].device))
             self._pk_key = None
         key = _param_key(params)
         if key != self._pk_key:
             self._plan[1].refresh()
+            ops.split_bf16x3(self._pk["Wh"], self._pk["Wx3"])
             self._pk_key = key
         return self._pk
 

@@ -323,7 +323,7 @@ __device__ __forceinline__ void fetch_uniforms(const float* __restrict__ U, unsi
   }
 }
 
-__global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge_group_t> T, float tau,
+__global__ __launch_bounds__(256, 2) void edge_mlp_gumbel_kernel(GroupTable<gn_edge_group_t> T, float tau,
                                                               unsigned long long seed,
                                                               const unsigned long long* __restrict__ offset_dev) {
   const int gi = find_group(T, blockIdx.x);
@@ -363,6 +363,100 @@ __global__ __launch_bounds__(256) void edge_mlp_gumbel_kernel(GroupTable<gn_edge
   //   A: T0 T1 S0 T2 S1 T3 S2 S3        (T = Wi0 tile, S = the two Wi1 slices over it: 8 steps each)
   //   B: T0 T1 S0 T2 S1 ... T7 S6 S7    (T = Wd0 tile: 8 steps, S = the Wd1 slice over it: 4 steps)
   // followed by 8 steps of padding, because the ring always reads 8 steps ahead.
+  if (G.Wx3 != nullptr) {
+    // ---- the same two layer pairs with fp32-accurate products on the bf16 cores (x = x1+x2+x3, six part-products
+    // per k = 16 sub-step), hidden-tile by hidden-tile exactly as below: tile t of the first layer (4 sub-steps),
+    // ReLU, its bf16 parts, then its slice of the second layer (4 sub-steps for z's two tiles, 2 for the logits
+    // tile).  80 sub-steps per row block, walked linearly through the three-part image of the hidden-tile-major
+    // weight stream; a 4-sub-step register ring is refilled in place (24 MFMAs ahead).
+    const int lane = rb.lane, h = rb.h;
+    const float* bi0 = G.bias;
+    const float* bi1 = G.bias + 128;
+    const float* bd0 = G.bias + 192;
+    const float* bd1 = G.bias + 448;
+    const f32x4* Wx = reinterpret_cast<const f32x4*>(G.Wx3) + lane;     // sub-step s, part p: (s*3 + p)*64
+    f32x4 wq[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) wq[u] = Wx[u * 64];
+    constexpr int kSub = 80;
+    auto sub = [&](int s, const bf16x8 (&x)[3], f32x16& acc) {
+      const int u = (s & 3) * 3;
+      const bf16x8 w1 = __builtin_bit_cast(bf16x8, wq[u + 0]);
+      const bf16x8 w2 = __builtin_bit_cast(bf16x8, wq[u + 1]);
+      const bf16x8 w3 = __builtin_bit_cast(bf16x8, wq[u + 2]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x[0], acc, 0, 0, 0);
+      const int sn = s + 4 < kSub ? s + 4 : s + 4 - kSub;     // (past the end: any valid piece)
+      const f32x4* src = Wx + (size_t)sn * 3 * 64;
+      wq[u + 0] = src[0];
+      wq[u + 1] = src[64];
+      wq[u + 2] = src[128];
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto parts = [&](const f32x16& v, bf16x8 (&x)[2][3]) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          __bf16 a, b, c;
+          split3(v[8 * hf + jj], a, b, c);
+          x[hf][0][jj] = a;
+          x[hf][1][jj] = b;
+          x[hf][2][jj] = c;
+        }
+    };
+    bf16x8 xi[2][2][3];      // parts of the current layer pair's input (edges, then z)
+    parts(in[0], xi[0]);
+    parts(in[1], xi[1]);
+    z[0] = load_bias_tile(bi1, h);
+    z[1] = load_bias_tile(bi1 + 32, h);
+    lg[0] = load_bias_tile(bd1, h);
+    // ---- pair A: 4 hidden tiles x (4 + 4) sub-steps ----
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x16 hid = load_bias_tile(bi0 + 32 * t, h);
+      sub(8 * t + 0, xi[0][0], hid);
+      sub(8 * t + 1, xi[0][1], hid);
+      sub(8 * t + 2, xi[1][0], hid);
+      sub(8 * t + 3, xi[1][1], hid);
+      relu16(hid);
+      if (G.keep_z1 != nullptr) {
+        f32x16 tmp[1] = {hid};
+        store_rows<1>(G.keep_z1 + 32 * t, 128, rb.row, h, rb.live, tmp);
+      }
+      bf16x8 xh[2][3];
+      parts(hid, xh);
+      sub(8 * t + 4, xh[0], z[0]);
+      sub(8 * t + 5, xh[1], z[0]);
+      sub(8 * t + 6, xh[0], z[1]);
+      sub(8 * t + 7, xh[1], z[1]);
+    }
+    if (G.keep_z != nullptr) store_rows<2>(G.keep_z, GN_FEAT, rb.row, h, rb.live, z);
+    parts(z[0], xi[0]);
+    parts(z[1], xi[1]);
+    // ---- pair B: 8 hidden tiles x (4 + 2) sub-steps ----
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f32x16 hid = load_bias_tile(bd0 + 32 * t, h);
+      sub(32 + 6 * t + 0, xi[0][0], hid);
+      sub(32 + 6 * t + 1, xi[0][1], hid);
+      sub(32 + 6 * t + 2, xi[1][0], hid);
+      sub(32 + 6 * t + 3, xi[1][1], hid);
+      relu16(hid);
+      if (G.keep_dh1 != nullptr) {
+        f32x16 tmp[1] = {hid};
+        store_rows<1>(G.keep_dh1 + 32 * t, 256, rb.row, h, rb.live, tmp);
+      }
+      bf16x8 xh[2][3];
+      parts(hid, xh);
+      sub(32 + 6 * t + 4, xh[0], lg[0]);
+      sub(32 + 6 * t + 5, xh[1], lg[0]);
+    }
+  } else
   {
     const int lane = rb.lane, h = rb.h;
     const float* bi0 = G.bias;

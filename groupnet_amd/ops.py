@@ -53,6 +53,9 @@ def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
 launch_probe = None
 
 
+BF16X6 = os.environ.get("GN_AGG_BF16X6", "1") != "0"   # fp32-accurate products on the bf16 cores (agg, edge kernels)
+
+
 class _Probed:
     __slots__ = ("name", "flops", "probe")
 
@@ -460,8 +463,10 @@ def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5, keep: Opti
             mk = lambda w: torch.empty((B * E, w), dtype=edges.dtype, device=edges.device)
             keep.append(dict(z1=mk(128), z=mk(64), dh1=mk(256), lgf=mk(32)))
             kp = tuple(keep[-1][n].data_ptr() for n in ("z1", "z", "dh1", "lgf"))
+        wx3 = pk.get("Wx3") if BF16X6 else None
         arr[g] = _lib.EdgeGroup(edges.data_ptr(), u_ptr, pk["W"].data_ptr(), pk["bias"].data_ptr(),
-                                edge_feat.data_ptr(), 0 if dist is None else dist.data_ptr(), off, B * E, K, sym_N, *kp)
+                                edge_feat.data_ptr(), 0 if dist is None else dist.data_ptr(), off, B * E, K, sym_N, *kp,
+                                0 if wx3 is None else wx3.data_ptr())
         outs.append((edge_feat, dist))
     flops = sum(int(a.rows) for a in arr) * 2 * (64 * 128 + 128 * 64 + 64 * 256 + 256 * 32)
     with torch.cuda.device(e0.device), _Probed("edge_mlp_gumbel_kernel", flops):
@@ -526,9 +531,6 @@ class PairSpec:
 
     def __init__(self, A: Tensor):
         self.A = A
-
-
-BF16X6 = os.environ.get("GN_AGG_BF16X6", "1") != "0"   # pair form: fp32-accurate products on the bf16 cores
 
 
 def split_bf16x3(packed: Tensor, out: Optional[Tensor] = None) -> Tensor:

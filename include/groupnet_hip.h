@@ -216,6 +216,10 @@ typedef struct {
   float* keep_z;
   float* keep_dh1;
   float* keep_lgf;
+  const void* Wx3;   /* optional: the four layers as three bf16 parts (gn_split_bf16x3_f32) of the hidden-tile-major
+                        fp32 stream — per hidden tile t of init_MLP: [Wi0(t,in0), Wi0(t,in1), Wi1(0,t), Wi1(1,t)], then
+                        per hidden tile t of [Wd0]: [Wd0(t,in0), Wd0(t,in1), Wd1(0,t)] — 40 tiles; when present the
+                        kernel forms fp32-accurate products on the bf16 cores */
 } gn_edge_group_t;
 int gn_edge_mlp_gumbel_f32(const gn_edge_group_t* groups, int n_groups, float tau, unsigned long long seed,
                            const unsigned long long* offset_dev, gn_stream_t stream);
