@@ -53,7 +53,7 @@ def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
 launch_probe = None
 
 
-BF16X6 = os.environ.get("GN_AGG_BF16X6", "1") != "0"   # fp32-accurate products on the bf16 cores (agg, edge kernels)
+BF16X6 = os.environ.get("GN_BF16X6", "1") != "0"   # fp32-accurate products on the bf16 cores (agg, edge kernels)
 
 
 class _Probed:

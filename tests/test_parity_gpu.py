@@ -941,3 +941,26 @@ def test_pair_form_on_the_bf16_cores_is_fp32_accurate():
     scale = float(plain.abs().max())
     assert float((got - ref).abs().max()) <= 2e-6 * scale
     assert float((got - plain).abs().max()) <= 4e-6 * scale
+
+
+def test_bf16_core_paths_match_fp32_mfma_paths_at_full_size():
+    """B=512, N=11, scales {2,5,11}: the whole multiscale forward with the edge and aggregation kernels on the
+    bf16 cores (three-part split, six products) against the same forward with every kernel on the fp32 matrix
+    cores (`ops.BF16X6 = False`), same noise: identical incidence, features within 2e-6 of the feature scale."""
+    from groupnet_amd import ops
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    torch.manual_seed(77)
+    B, N = 512, 11
+    blk = MultiScaleHGNN([2, 5, 11]).to(dev()).eval()
+    f = torch.randn(B, N, 64, device=dev())
+    noise = [[torch.rand(s, device=dev())] for s in blk.noise_shapes(B, N)]
+    with torch.no_grad():
+        assert ops.BF16X6
+        a, Ha = blk(f, noise_u=noise)
+        ops.BF16X6 = False
+        try:
+            b, Hb = blk(f, noise_u=noise)
+        finally:
+            ops.BF16X6 = True
+    assert torch.equal(Ha, Hb)
+    assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
