@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="consecutive steps are issued round-robin on this many HIP streams (each with its own "
                          "captured graph and output buffers), so the tail of one step overlaps the head of the next")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the training-step side measurement")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the multi-GPU code path (process group, bucketed all-gather) with one rank")
     args = ap.parse_args()
@@ -366,7 +367,7 @@ def main():
             G.set_noise_mode("host")
             # ---- one training step (fwd + loss + bwd + SGD) replayed from one hipGraph ------
             try:
-                train = train_step_leg(N, Bl, dev) if world == 1 else None
+                train = train_step_leg(N, Bl, dev) if (world == 1 and not args.no_train_leg) else None
             except Exception as e:      # the headline forward numbers stand on their own
                 train = dict(error=f"{type(e).__name__}: {e}")
 
