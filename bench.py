@@ -387,8 +387,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"MS-HGNN forward: affinity + top-k + pairwise + hyper scales {SCALES}, "
-                                   f"N={N} agents, {Bl} scenes per GPU (global batch {B_total}), fp32, "
-                                   f"device Philox noise, {'eager' if args.no_graph else f'hipGraph replay on {S} alternating streams'}"
+                                   f"N={N} agents, {Bl} scenes per GPU (global batch {B_total}), fp32 in and out"
+                                   + (" (edge and aggregation MLPs: fp32-accurate three-part bf16 products on the bf16 "
+                                      "matrix cores, other kernels fp32 MFMA), " if ops.BF16X6 else ", ")
+                                   + f"device Philox noise, {'eager' if args.no_graph else f'hipGraph replay on {S} alternating streams'}"
                                    + (f", + RCCL all-gather of the (B,N,320) embeddings, one call per {S} steps, "
                                       f"overlapped on a side stream" if distributed else ""),
                        "global_batch": B_total, "agents": N, "scales": SCALES,
