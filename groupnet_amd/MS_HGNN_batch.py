@@ -232,13 +232,14 @@ class MLP_dict_softmax(nn.Module):
             plan.vector(bo + 448, f1.bias, place=K)
             plan.finish()
             self._plan = (plan.sources[:0] + tuple(p.data_ptr() for p in params), plan)
-            self._pk = dict(W=plan.view(w0, w_len), bias=plan.view(bo, 480), Wh=plan.view(wh, 40 * T),
-                            Wx3=torch.empty(40 * 2 * 3 * 64 * 8, dtype=torch.int16, device=params[0].device))
+            xi = ops.XImages()
+            xi.add("edge", plan.view(wh, 40 * T))
+            self._pk = dict(W=plan.view(w0, w_len), bias=plan.view(bo, 480), xi=xi)
             self._pk_key = None
         key = _param_key(params)
-        if key != self._pk_key:
+        if key != self._pk_key or _volatile(params):
             self._plan[1].refresh()
-            ops.split_bf16x3(self._pk["Wh"], self._pk["Wx3"])
+            self._pk["xi"].bump()
             self._pk_key = key
         return self._pk
 
@@ -304,16 +305,17 @@ class edge_aggregation(nn.Module):
             self._plan = (tuple(p.data_ptr() for p in params), plan)
             self._pk = dict(W=plan.view(w0, w_len), b1=plan.view(b1o, K * 128).view(K, 128),
                             b2=plan.view(b2o, K * 64).view(K, 64), W1cat=plan.view(w1c, K * 8 * T),
-                            b1half=plan.view(bho, K * 128), W2t=plan.view(w2t, K * 8 * T),
-                            W2x3=torch.empty(K * 8 * 2 * 3 * 64 * 8, dtype=torch.int16, device=params[0].device),
-                            W12=plan.view(w12, K * 16 * T),
-                            W12x3=torch.empty(K * 16 * 2 * 3 * 64 * 8, dtype=torch.int16, device=params[0].device))
+                            b1half=plan.view(bho, K * 128), W2t=plan.view(w2t, K * 8 * T))
+            xi = ops.XImages()
+            xi.add("W2t", self._pk["W2t"])                   # layer 2 per hidden tile (pair form)
+            xi.add("W12", plan.view(w12, K * 16 * T))        # both layers, hidden-tile-major (two-layer form)
+            xi.add("W1cat", self._pk["W1cat"])               # layer 1 of all types per node (node stage)
+            self._pk["xi"] = xi
             self._pk_key = None
         key = _param_key(params)
-        if key != self._pk_key:
+        if key != self._pk_key or _volatile(params):
             self._plan[1].refresh()
-            ops.split_bf16x3(self._pk["W2t"], self._pk["W2x3"])     # layer 2 as three bf16 parts (pair form)
-            ops.split_bf16x3(self._pk["W12"], self._pk["W12x3"])    # both layers, hidden-tile-major (two-layer form)
+            self._pk["xi"].bump()
             self._pk_key = key
         return self._pk
 
@@ -333,6 +335,16 @@ class edge_aggregation(nn.Module):
 def _param_key(params: Iterable[nn.Parameter]):
     """Cheap fingerprint of a parameter set: storage address + in-place version counter."""
     return tuple((p.data_ptr(), p._version) for p in params)
+
+
+def _volatile(params: Iterable[nn.Parameter]) -> bool:
+    """Whether the packed-image cache must not be trusted for this call.  The fingerprint above misses writes
+    made through ``p.data`` / raw pointers (they do not bump ``_version``) — the idiom of hand-written
+    optimizers, EMA updates, weight clamping and the reference's own ``m.bias.data.fill_`` re-initialisation.
+    While autograd is recording for these parameters (a training step) every call therefore re-runs the one
+    refresh launch of its pack plan; only inference (no-grad / frozen parameters) trusts the cache, and code
+    that rewrites weights there behind autograd's back calls `invalidate_weight_caches`."""
+    return torch.is_grad_enabled() and any(p.requires_grad for p in params)
 
 
 def invalidate_weight_caches(module: nn.Module) -> None:
@@ -403,17 +415,31 @@ class _MessagePassing(nn.Module):
             plan.block(wpq, a0.weight, 2, c0=0, cols=D)
             plan.block(wpq, a0.weight, 2, c0=D, cols=D, place_r=32)
             w_len = plan.size - w0
+            # the same chain hidden-tile-major (source of the bf16-core image): per hidden tile t of layer 0 the
+            # tiles [W0(t,in0), W0(t,in1), W1(0,t), W1(1,t)], then Wpq as above: 36 tiles = 72 sub-steps
+            T = plan.TILE
+            wc = plan.alloc(36 * T)
+            for t in range(8):
+                base = wc + 4 * t * T
+                plan.block(base, s0.weight, 2, r0=32 * t, rows=32)
+                plan.block(base + 2 * T, s1.weight, 1, r0=0, c0=32 * t, rows=32, cols=32)
+                plan.block(base + 3 * T, s1.weight, 1, r0=32, c0=32 * t, rows=32, cols=32)
+            plan.block(wc + 32 * T, a0.weight, 2, c0=0, cols=D)
+            plan.block(wc + 32 * T, a0.weight, 2, c0=D, cols=D, place_r=32)
             bo = plan.alloc(256 + 64 + 64)
             plan.vector(bo, s0.bias)
             plan.vector(bo + 256, s1.bias)
             plan.vector(bo + 320, a0.bias)
             plan.finish()
-            pk = dict(W=plan.view(w0, w_len), bias=plan.view(bo, 384),
+            xi = ops.XImages()
+            xi.add("chain", plan.view(wc, 36 * T))
+            pk = dict(W=plan.view(w0, w_len), bias=plan.view(bo, 384), xi=xi,
                       w2=a1.weight.detach()[0], b2=a1.bias.detach())    # views of the parameters: no host sync
             hit = self._pk_n2e[idx] = [ptrs, pk, plan, None]
         key = _param_key(params)
-        if key != hit[3]:
+        if key != hit[3] or _volatile(params):
             hit[2].refresh()
+            hit[1]["xi"].bump()
             hit[3] = key
         return hit[1]
 
@@ -428,16 +454,33 @@ class _MessagePassing(nn.Module):
             plan.matrix(l1.weight)
             w_len = plan.size - w0
             pad = lambda n: (n + 31) // 32 * 32
-            bo = plan.alloc(pad(l0.out_features) + pad(l1.out_features))
+            din, dh, dout = l0.in_features, l0.out_features, l1.out_features
+            xi = ops.XImages()
+            wh = n_t = 0
+            if dout <= 64 and din % 32 == 0 and dh % 32 == 0:
+                # hidden-tile-major (source of the bf16-core image): per hidden tile t [W0(t, in *), W1(*, t)]
+                T, IT, HT, OT = plan.TILE, din // 32, dh // 32, (dout + 31) // 32
+                n_t = HT * (IT + OT)
+                wh = plan.alloc(n_t * T)
+                for t in range(HT):
+                    base = wh + t * (IT + OT) * T
+                    plan.block(base, l0.weight, IT, r0=32 * t, rows=32)
+                    for o in range(OT):
+                        plan.block(base + (IT + o) * T, l1.weight, 1, r0=32 * o, c0=32 * t, rows=min(32, dout - 32 * o),
+                                   cols=32)
+            bo = plan.alloc(pad(dh) + pad(dout))
             plan.vector(bo, l0.bias)
-            plan.vector(bo + pad(l0.out_features), l1.bias)
+            plan.vector(bo + pad(dh), l1.bias)
             plan.finish()
-            pk = dict(W=plan.view(w0, w_len), bias=plan.view(bo, pad(l0.out_features) + pad(l1.out_features)),
-                      din=l0.in_features, dh=l0.out_features, dout=l1.out_features)
+            if n_t:
+                xi.add("mlp2", plan.view(wh, n_t * plan.TILE))
+            pk = dict(W=plan.view(w0, w_len), bias=plan.view(bo, pad(dh) + pad(dout)), xi=xi,
+                      din=din, dh=dh, dout=dout)
             hit = self._pk_mlp[id(mlp)] = [ptrs, pk, plan, None]
         key = _param_key(params)
-        if key != hit[3]:
+        if key != hit[3] or _volatile(params):
             hit[2].refresh()
+            hit[1]["xi"].bump()
             hit[3] = key
         return hit[1]
 
@@ -457,6 +500,8 @@ class _MessagePassing(nn.Module):
     def _forward_autograd(self, h: Tensor, H: Optional[Tensor], noise_u, out: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
         """Training path: fused forward + HIP backward through torch.autograd."""
         from .backward import MSHGNNFunction
+        if h.dtype != torch.float32:
+            raise NotImplementedError("the bf16 twins are forward-only: run them under torch.no_grad()")
         if out is not None:
             raise ValueError("out= is an inference-time extra; under autograd the module returns a new tensor")
         return MSHGNNFunction.apply((self,), (H,), (noise_u,), h, *_plist(self))
@@ -496,10 +541,21 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
                 raise ValueError(f"noise_u: {nmp} uniform tensors of shape ({B},{Es[i]},{mods[i].edge_types}) needed")
         return _draw_uniform((B, Es[i], mods[i].edge_types), hs[i].device)
 
+    twin = hs[0].dtype == torch.bfloat16
+    if twin and traces is not None:
+        raise NotImplementedError("the bf16 twins are forward-only")
+    pair_A: List[Optional[Tensor]] = [None] * n     # per-node first layer of the typed MLP (pairwise groups)
+
     def node2edge(xs: Sequence[Tensor], idx: int) -> List[Tensor]:
         pks = [m._packed_n2e(idx) for m in mods]
         keep = [] if traces is not None else None
-        xpq = ops.node_mlp_grouped([(x, pk) for x, pk in zip(xs, pks)], keep)
+        # the node rows entering this round also feed the typed aggregation MLP that closes it: for the pairwise
+        # graph its first layer is linear in the two nodes (eo = ori_i + ori_j) and runs once per NODE, in this
+        # same launch (fp32 path; the bf16 twin runs both layers per pair on the matrix cores instead)
+        specs = [((m.edge_aggregation_list[idx]._packed(), m.edge_aggregation_list[idx].edge_types)
+                  if (sy and not twin) else None) for m, sy in zip(mods, syms)]
+        xpq, As = ops.node_stage_grouped([(x, pk) for x, pk in zip(xs, pks)], keep, specs)
+        pair_A[:] = As
         edges = ops.node2edge_grouped([(xp, pq, H, pk["w2"], pk["b2"], sy)
                                        for (xp, pq), H, pk, sy in zip(xpq, Hs, pks, syms)])
         if traces is not None:      # kept for the backward: nothing of this round is re-computed there
@@ -523,10 +579,13 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
         items = []
         for i in range(n):
             pk, K = aggs[i]._packed(), aggs[i].edge_types
-            if syms[i]:
+            if syms[i] and not twin:
                 # pairwise: eo = ori_i + ori_j makes the typed MLP's first layer linear in the two nodes, so
-                # it runs once per node (N rows instead of N(N+1)/2 pairs); the pair form does the rest
-                src = ops.PairSpec(ops.node_linear(oris[i], pk["W1cat"], pk["b1half"], K * 128))
+                # it ran once per node (N rows instead of N(N+1)/2 pairs) in this round's node stage; the
+                # pair form does the rest
+                src = ops.PairSpec(pair_A[i])
+            elif syms[i]:
+                src = ops.GatherSpec(oris[i], None, True)     # bf16 twin: both layers per unordered pair
             elif N <= _FUSED_GATHER_MAX_N:
                 src = ops.GatherSpec(oris[i], Hs[i], False)   # eo = H @ ori formed inside the kernel
             else:
@@ -608,7 +667,7 @@ class MS_HGNN_oridinary(_MessagePassing):
         """``out`` (optional): where node_feat is written, e.g. a column block of the caller's
         concatenated feature tensor.  Under autograd (an input or a parameter requires grad) the call
         goes through `groupnet_amd.backward.MSHGNNFunction`: same fused forward, HIP backward."""
-        ops._req(h_states, "h_states", (None, None, self.h_dim))
+        ops._req(h_states, "h_states", (None, None, self.h_dim), ops._ACT_DTYPES)
         N = h_states.shape[1]
         if h_states.shape[0] and N and _needs_grad(self, h_states):
             return self._forward_autograd(h_states, None, noise_u, out)
@@ -646,6 +705,8 @@ class MS_HGNN_hyper(_MessagePassing):
 
     def init_adj_attention(self, feat, feat_corr, scale_factor=2):
         """H (B,E,N) from the affinity matrix (model/MS_HGNN_batch.py:372-388)."""
+        if feat_corr.dtype == torch.bfloat16:     # ranked in fp32 either way; fp32 corr keeps near-ties apart
+            feat_corr = feat_corr.float()
         ops._req(feat_corr, "corr", (feat.shape[0], feat.shape[1], feat.shape[1]))
         return ops.topk_incidence(feat_corr, [int(scale_factor)])[0]
 
@@ -668,7 +729,7 @@ class MS_HGNN_hyper(_MessagePassing):
     def forward(self, h_states, corr, noise_u=None, H=None, out=None):
         """``H`` (optional) lets a caller that already built the incidence for every scale in one
         fused launch (``ops.affinity_topk``) hand it in; by default it is built here from ``corr``."""
-        ops._req(h_states, "h_states", (None, None, self.h_dim))
+        ops._req(h_states, "h_states", (None, None, self.h_dim), ops._ACT_DTYPES)
         if h_states.shape[0] and _needs_grad(self, h_states):
             # H is a constant of the backward (top-k selection has no gradient; corr is only used to build it)
             if H is None:
@@ -687,4 +748,4 @@ class MS_HGNN_hyper(_MessagePassing):
         else:
             ops._req(H, "H", (h_states.shape[0], None, h_states.shape[1]))
         node_feat, factor = self._run(h_states, H, H.shape[1], noise_u, out)
-        return node_feat, factor, H
+        return node_feat, factor, (H if H.dtype == h_states.dtype else H.to(h_states.dtype))    # type_as(feat), :376,384

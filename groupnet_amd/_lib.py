@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -26,7 +26,8 @@ _SZ = ctypes.c_size_t
 _U64 = ctypes.c_ulonglong
 
 class NodeGroup(ctypes.Structure):      # gn_node_group_t
-    _fields_ = [("x", _P), ("W", _P), ("bias", _P), ("xp", _P), ("pq", _P), ("hid_out", _P)]
+    _fields_ = [("x", _P), ("W", _P), ("bias", _P), ("xp", _P), ("pq", _P), ("hid_out", _P), ("Wx", _P),
+                ("WAx", _P), ("bA", _P), ("A", _P), ("KA", _I)]
 
 
 class N2EGroup(ctypes.Structure):       # gn_n2e_group_t
@@ -36,7 +37,7 @@ class N2EGroup(ctypes.Structure):       # gn_n2e_group_t
 class EdgeGroup(ctypes.Structure):      # gn_edge_group_t
     _fields_ = [("edges", _P), ("U", _P), ("W", _P), ("bias", _P), ("edge_feat", _P), ("dist", _P),
                 ("philox_offset", _U64), ("rows", _I), ("K", _I), ("sym_N", _I), ("keep_z1", _P), ("keep_z", _P),
-                ("keep_dh1", _P), ("keep_lgf", _P), ("Wx3", _P)]
+                ("keep_dh1", _P), ("keep_lgf", _P), ("Wx", _P)]
 
 
 class GatherGroup(ctypes.Structure):    # gn_gather_group_t
@@ -45,7 +46,7 @@ class GatherGroup(ctypes.Structure):    # gn_gather_group_t
 
 class AggGroup(ctypes.Structure):       # gn_agg_group_t
     _fields_ = [("eo", _P), ("edge_feat", _P), ("W", _P), ("b1", _P), ("b2", _P), ("feat", _P), ("rows", _I),
-                ("K", _I), ("ori", _P), ("H", _P), ("E", _I), ("N", _I), ("sym", _I), ("A", _P), ("W2x3", _P), ("W12x3", _P)]
+                ("K", _I), ("ori", _P), ("H", _P), ("E", _I), ("N", _I), ("sym", _I), ("A", _P), ("W2x", _P), ("W12x", _P)]
 
 
 class ScatterGroup(ctypes.Structure):   # gn_scatter_group_t
@@ -54,7 +55,7 @@ class ScatterGroup(ctypes.Structure):   # gn_scatter_group_t
 
 class Mlp2Group(ctypes.Structure):      # gn_mlp2_group_t
     _fields_ = [("x", _P), ("W", _P), ("bias", _P), ("y", _P), ("feat", _P), ("H", _P), ("ori", _P), ("E", _I),
-                ("sym", _I), ("in_out", _P), ("hid_out", _P)]
+                ("sym", _I), ("in_out", _P), ("hid_out", _P), ("Wx", _P)]
 
 
 class BlockExtras(ctypes.Structure):    # gn_block_extras_t
@@ -85,18 +86,27 @@ SIGNATURES = {
     "gn_listall_incidence_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "gn_affinity_topk_f32": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_I), _I, _I, _I, _I,
                                   ctypes.POINTER(BlockExtras), _P]),
+    "gn_affinity_topk_bf16": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_I), _I, _I, _I, _I,
+                                   ctypes.POINTER(BlockExtras), _P]),
     "gn_packed_elems": (_SZ, [_I, _I]),
     "gn_pack_linear_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "gn_split_bf16x3_f32": (_I, [_P, _P, _I, _P]),
+    "gn_split_bf16_f32": (_I, [_P, _P, _I, _I, _P]),
     "gn_pack_segments_f32": (_I, [_P, _I, _I, _P]),
     "gn_node_mlp_f32": (_I, [ctypes.POINTER(NodeGroup), _I, _I, _P]),
+    "gn_node_mlp_bf16": (_I, [ctypes.POINTER(NodeGroup), _I, _I, _P]),
     "gn_node2edge_f32": (_I, [ctypes.POINTER(N2EGroup), _I, _I, _I, _P]),
+    "gn_node2edge_bf16": (_I, [ctypes.POINTER(N2EGroup), _I, _I, _I, _P]),
     "gn_edge_mlp_gumbel_f32": (_I, [ctypes.POINTER(EdgeGroup), _I, _F, _U64, _P, _P]),
+    "gn_edge_mlp_gumbel_bf16": (_I, [ctypes.POINTER(EdgeGroup), _I, _F, _U64, _P, _P]),
     "gn_agg_gather_f32": (_I, [ctypes.POINTER(GatherGroup), _I, _I, _I, _P]),
+    "gn_agg_gather_bf16": (_I, [ctypes.POINTER(GatherGroup), _I, _I, _I, _P]),
     "gn_agg_mlp_f32": (_I, [ctypes.POINTER(AggGroup), _I, _P]),
+    "gn_agg_mlp_bf16": (_I, [ctypes.POINTER(AggGroup), _I, _P]),
     "gn_node_linear_f32": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "gn_agg_scatter_f32": (_I, [ctypes.POINTER(ScatterGroup), _I, _I, _I, _F, _P]),
+    "gn_agg_scatter_bf16": (_I, [ctypes.POINTER(ScatterGroup), _I, _I, _I, _F, _P]),
     "gn_mlp2_f32": (_I, [ctypes.POINTER(Mlp2Group), _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "gn_mlp2_bf16": (_I, [ctypes.POINTER(Mlp2Group), _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "gn_gemm_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _F, _P]),
     "gn_gemm_grouped_f32": (_I, [ctypes.POINTER(GemmDesc), _I, _P]),
     "gn_typed_bwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, ctypes.c_longlong, _I, _I, _P]),

@@ -4,7 +4,7 @@
 // by HBM, so the design rules are: coalesced 16-byte global accesses, the
 // scene's N x 64 feature tile and N x N (or E x N) incidence tile staged ONCE through LDS,
 // wavefront-shuffle reductions, and grids of >> 256 workgroups.
-#include "gn_common.hpp"
+#include "gn_mlp_common.hpp"
 
 namespace {
 
@@ -32,7 +32,9 @@ struct ScaleList {
 };
 
 // rank of column c inside `row` (LDS, N entries) and the writes of every scale
+template <typename T>
 __device__ __forceinline__ void emit_incidence(const float* row, int N, int b, int i, int c, const ScaleList& sl) {
+  T* H_cat = reinterpret_cast<T*>(sl.H_cat);   // the concatenation is what the caller returns: storage type T
   const float v = row[c];
   int rank = 0;
   for (int j = 0; j < N; ++j) rank += beats(row[j], j, v, c) ? 1 : 0;
@@ -40,12 +42,12 @@ __device__ __forceinline__ void emit_incidence(const float* row, int N, int b, i
     if (sl.k[s] == N) {
       if (i == 0) {
         sl.H[s][(size_t)b * N + c] = 1.f;
-        if (sl.H_cat) sl.H_cat[((size_t)b * sl.cat_rows + sl.cat_off[s]) * N + c] = 1.f;
+        if (H_cat) st1(H_cat + ((size_t)b * sl.cat_rows + sl.cat_off[s]) * N + c, 1.f);
       }
     } else {
       const float v = rank < sl.k[s] ? 1.f : 0.f;
       sl.H[s][((size_t)b * N + i) * N + c] = v;
-      if (sl.H_cat) sl.H_cat[((size_t)b * sl.cat_rows + sl.cat_off[s] + i) * N + c] = v;
+      if (H_cat) st1(H_cat + ((size_t)b * sl.cat_rows + sl.cat_off[s] + i) * N + c, v);
     }
   }
 }
@@ -53,14 +55,15 @@ __device__ __forceinline__ void emit_incidence(const float* row, int N, int b, i
 // One workgroup per scene.  f rows are normalised into LDS (stride D+4 floats keeps the
 // 16-byte row reads of different rows on different banks), corr is formed in LDS, optionally
 // written out, and ranked in place.  Needs N*(D+4 + N)*4 bytes of LDS.
-__global__ __launch_bounds__(kBlock) void affinity_topk_kernel(const float* __restrict__ f, float* __restrict__ corr,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void affinity_topk_kernel(const T* __restrict__ f, float* __restrict__ corr,
                                                                ScaleList sl, int N, int D, gn_block_extras_t ex) {
   extern __shared__ __align__(16) float lds[];
   const int b = blockIdx.x;
   const int ldq = D + 4;
   float* q = lds;             // N x ldq
   float* cr = lds + N * ldq;  // N x N
-  const float* fb = f + (size_t)b * N * D;
+  const T* fb = f + (size_t)b * N * D;
   const int d4 = D >> 2;
   if (ex.counter != nullptr && b == 0 && threadIdx.x == 0) *ex.counter += ex.counter_add;
   float* xs = cr + N * N;  // N x x_dim raw inputs (embedding form only)
@@ -85,10 +88,10 @@ __global__ __launch_bounds__(kBlock) void affinity_topk_kernel(const float* __re
       }
       *reinterpret_cast<f32x4*>(ex.f_contig + ((size_t)b * N + r) * D + 4 * cc) = v;
     } else {
-      v = *reinterpret_cast<const f32x4*>(fb + (size_t)r * D + 4 * cc);
+      v = ld4(fb + (size_t)r * D + 4 * cc);
     }
     *reinterpret_cast<f32x4*>(q + r * ldq + 4 * cc) = v;
-    if (ex.f_out != nullptr) *reinterpret_cast<f32x4*>(ex.f_out + ((size_t)b * N + r) * ex.f_out_ld + 4 * cc) = v;
+    if (ex.f_out != nullptr) st4(reinterpret_cast<T*>(ex.f_out) + ((size_t)b * N + r) * ex.f_out_ld + 4 * cc, v);
   }
   __syncthreads();
   // row norms: one wave per row, lanes stride the row
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void affinity_topk_kernel(const float* __re
   __syncthreads();
   for (int idx = threadIdx.x; idx < N * N; idx += kBlock) {
     const int i = idx / N, c = idx - i * N;
-    emit_incidence(cr + i * N, N, b, i, c, sl);
+    emit_incidence<T>(cr + i * N, N, b, i, c, sl);
   }
 }
 
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void topk_incidence_kernel(const float* __r
   __syncthreads();
   for (int idx = threadIdx.x; idx < nr * N; idx += kBlock) {
     const int i = idx / N, c = idx - i * N;
-    emit_incidence(lds + i * N, N, b, i0 + i, c, sl);
+    emit_incidence<float>(lds + i * N, N, b, i0 + i, c, sl);
   }
 }
 
@@ -195,13 +198,13 @@ __global__ __launch_bounds__(kBlock) void topk_incidence_kernel(const float* __r
 // group tables (kernel arguments, by value): one launch serves the same stage of several modules
 // --------------------------------------------------------------------------------------------
 template <typename G>
-struct GroupTable {
+struct WaveTable {
   G g[GN_MAX_GROUPS];
   long long first[GN_MAX_GROUPS + 1];  // prefix of work items (meaning depends on the kernel)
   int n;
 };
 template <typename G>
-__device__ __forceinline__ int find_group(const GroupTable<G>& t, long long item) {
+__device__ __forceinline__ int find_wave_group(const WaveTable<G>& t, long long item) {
   int g = 0;
   while (g + 1 < t.n && item >= t.first[g + 1]) ++g;
   return g;
@@ -213,15 +216,16 @@ __device__ __forceinline__ int find_group(const GroupTable<G>& t, long long item
 // Hyper modules: one wave per hyperedge.  Members of the edge (nodes with H != 0) are compacted
 // into LDS; non-members enter the softmax only as exp(0 - max) terms, exactly as
 // softmax(att * H) treats them (MS_HGNN_batch.py:135-137,366-368).  `first` counts edges (waves).
-__global__ __launch_bounds__(kBlock) void node2edge_kernel(GroupTable<gn_n2e_group_t> T, int N) {
+template <typename TS>
+__device__ __forceinline__ void node2edge_hyper_body(const WaveTable<gn_n2e_group_t>& T, int N, int wg) {
   extern __shared__ __align__(16) float lds[];
   const int wave = gn_uniform((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
   const long long total = T.first[T.n];
-  const long long w_raw = (long long)blockIdx.x * (kBlock / 64) + wave;
+  const long long w_raw = (long long)wg * (kBlock / 64) + wave;
   const bool live = w_raw < total;  // dead waves redo the last edge and skip the store
   const long long w = live ? w_raw : total - 1;
-  const int gi = gn_uniform(find_group(T, w));
+  const int gi = gn_uniform(find_wave_group(T, w));
   const gn_n2e_group_t G = T.g[gi];
   const int E = G.E;
   const long long eg = w - T.first[gi];
@@ -247,11 +251,11 @@ __global__ __launch_bounds__(kBlock) void node2edge_kernel(GroupTable<gn_n2e_gro
   }
   __syncthreads();
 
-  const float* pqb = G.pq + (size_t)b * N * GN_FEAT;
-  const float* xpb = G.xp + (size_t)b * N * GN_FEAT;
+  const TS* pqb = reinterpret_cast<const TS*>(G.pq) + (size_t)b * N * GN_FEAT;
+  const TS* xpb = reinterpret_cast<const TS*>(G.xp) + (size_t)b * N * GN_FEAT;
   // Q_e = sum_n H[e,n] * Qn_n      (lanes 32..63 hold channel c of Qn)
   float qe = 0.f;
-  for (int m = 0; m < cnt; ++m) qe = fmaf(s_h[m], pqb[(size_t)s_idx[m] * GN_FEAT + lane], qe);
+  for (int m = 0; m < cnt; ++m) qe = fmaf(s_h[m], ld1(pqb + (size_t)s_idx[m] * GN_FEAT + lane), qe);
   const float qlo = __shfl(qe, 32 + c, GN_WAVE);  // both halves now see Q_e[c]
   const float w2c = G.w2[c];
   // att for two members per step: half h takes member 2*t + h
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_kernel(GroupTable<gn_n2e_gro
     const int m = m0 + h;
     const bool valid = m < cnt;
     const int n = valid ? s_idx[m] : 0;
-    const float p = pqb[(size_t)n * GN_FEAT + c];
+    const float p = ld1(pqb + (size_t)n * GN_FEAT + c);
     float t = valid ? w2c * fmaxf(p + qlo, 0.f) : 0.f;
     t = gn_half_sum(t);
     if (valid && c == 0) s_att[m] = t + *G.b2;
@@ -278,9 +282,9 @@ __global__ __launch_bounds__(kBlock) void node2edge_kernel(GroupTable<gn_n2e_gro
   for (int m = 0; m < cnt; ++m) {
     const float hv = s_h[m];
     const float wgt = expf(s_att[m] * hv - mx) / sum * hv;
-    acc = fmaf(wgt, xpb[(size_t)s_idx[m] * GN_FEAT + lane], acc);
+    acc = fmaf(wgt, ld1(xpb + (size_t)s_idx[m] * GN_FEAT + lane), acc);
   }
-  if (live) G.edges[(size_t)eg * GN_FEAT + lane] = acc;
+  if (live) st1(reinterpret_cast<TS*>(G.edges) + (size_t)eg * GN_FEAT + lane, acc);
 }
 
 // Pairwise module (MS_HGNN_oridinary): edge e = i*N + j touches i and j with weight 1 (2 on the
@@ -289,15 +293,16 @@ __global__ __launch_bounds__(kBlock) void node2edge_kernel(GroupTable<gn_n2e_gro
 // same channel), then walks bands of 256 edges: phase A one thread per edge evaluates the two
 // attention logits and the softmax weights, phase B the band's 256 x 16 float4 outputs are written
 // as consecutive 16-byte pieces.
-__global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group_t G, int B, int N, int SG,
-                                                                   int bands) {
+template <typename TS>
+__device__ __forceinline__ void node2edge_pairwise_body(const gn_n2e_group_t& G, int B, int N, int SG, int bands,
+                                                        int wg) {
   extern __shared__ __align__(16) float lds[];
   constexpr int LDP = GN_FEAT + 1;
   const bool sym = G.sym != 0;
   const float b2v = *G.b2;
   const int E = sym ? gn_pair_count(N) : N * N;   // edge rows per scene
-  const int b0 = (blockIdx.x / bands) * SG;
-  const int band = blockIdx.x % bands;
+  const int b0 = (wg / bands) * SG;
+  const int band = wg % bands;
   const int sg = min(SG, B - b0);
   float* s_xp = lds;                                // sg x N x 64
   float* s_pq = s_xp + (size_t)SG * N * GN_FEAT;    // sg x N x 65
@@ -305,13 +310,13 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
   float* s_w2 = s_w + 2 * kBlock;                   // 32
   int* s_ij = reinterpret_cast<int*>(s_w2 + 32);    // 256 packed (i, j) of the current band
   {
-    const f32x4* src = reinterpret_cast<const f32x4*>(G.xp + (size_t)b0 * N * GN_FEAT);
+    const TS* src = reinterpret_cast<const TS*>(G.xp) + (size_t)b0 * N * GN_FEAT;
     f32x4* dst = reinterpret_cast<f32x4*>(s_xp);
-    for (int idx = threadIdx.x; idx < sg * N * 16; idx += kBlock) dst[idx] = src[idx];
-    const float* psrc = G.pq + (size_t)b0 * N * GN_FEAT;
+    for (int idx = threadIdx.x; idx < sg * N * 16; idx += kBlock) dst[idx] = ld4(src + 4 * idx);
+    const TS* psrc = reinterpret_cast<const TS*>(G.pq) + (size_t)b0 * N * GN_FEAT;
     for (int idx = threadIdx.x; idx < sg * N * GN_FEAT; idx += kBlock) {
       const int r = idx >> 6, cc = idx & 63;
-      s_pq[r * LDP + cc] = psrc[idx];
+      s_pq[r * LDP + cc] = ld1(psrc + idx);
     }
     if (threadIdx.x < 32) s_w2[threadIdx.x] = G.w2[threadIdx.x];
   }
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
     }
     __syncthreads();
     const int nb = (int)min((long long)kBlock, hi - base);
-    f32x4* dst = reinterpret_cast<f32x4*>(G.edges + ((size_t)b0 * E + base) * GN_FEAT);
+    TS* dst = reinterpret_cast<TS*>(G.edges) + ((size_t)b0 * E + base) * GN_FEAT;
     for (int idx = threadIdx.x; idx < nb * 16; idx += kBlock) {
       const int t = idx >> 4, d = idx & 15;
       const long long eidx = base + t;
@@ -375,9 +380,30 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
       const f32x4 xj = reinterpret_cast<const f32x4*>(s_xp + (size_t)(s * N + j) * GN_FEAT)[d];
       f32x4 r = {fmaf(wj, xj[0], wi * xi[0]), fmaf(wj, xj[1], wi * xi[1]), fmaf(wj, xj[2], wi * xi[2]),
                  fmaf(wj, xj[3], wi * xi[3])};
-      dst[idx] = r;
+      st4(dst + 4 * idx, r);
     }
     __syncthreads();
+  }
+}
+
+// One launch for every module of a multiscale forward: the first `pair.first_wg[pair.n]` workgroups walk the
+// pairwise groups (scene-staged), the rest the hyperedges (one wave each).
+struct PairTable {
+  gn_n2e_group_t g[GN_MAX_GROUPS];
+  int first_wg[GN_MAX_GROUPS + 1];
+  int SG[GN_MAX_GROUPS], bands[GN_MAX_GROUPS];
+  int n;
+};
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void node2edge_kernel(WaveTable<gn_n2e_group_t> T, PairTable pair, int B, int N) {
+  const int wg = blockIdx.x;
+  const int n_pair_wgs = pair.first_wg[pair.n];
+  if (wg < n_pair_wgs) {
+    int g = 0;
+    while (g + 1 < pair.n && wg >= pair.first_wg[g + 1]) ++g;
+    node2edge_pairwise_body<TS>(pair.g[g], B, N, pair.SG[g], pair.bands[g], wg - pair.first_wg[g]);
+  } else {
+    node2edge_hyper_body<TS>(T, N, wg - n_pair_wgs);
   }
 }
 
@@ -390,6 +416,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_pairwise_kernel(gn_n2e_group
 struct GatherTable {
   gn_gather_group_t g[GN_MAX_GROUPS];
 };
+template <typename TS>
 __global__ __launch_bounds__(kBlock) void agg_gather_kernel(GatherTable T, int B, int N, int G, int TE) {
   extern __shared__ __align__(16) float lds[];
   const gn_gather_group_t Gr = T.g[blockIdx.z];
@@ -400,9 +427,9 @@ __global__ __launch_bounds__(kBlock) void agg_gather_kernel(GatherTable T, int B
   float* s_ori = lds;                           // g x N x 64
   float* s_H = lds + (size_t)G * N * GN_FEAT;   // g x te x N
   {
-    const f32x4* src = reinterpret_cast<const f32x4*>(Gr.ori + (size_t)b0 * N * GN_FEAT);
+    const TS* src = reinterpret_cast<const TS*>(Gr.ori) + (size_t)b0 * N * GN_FEAT;
     f32x4* dst = reinterpret_cast<f32x4*>(s_ori);
-    for (int idx = threadIdx.x; idx < g * N * (GN_FEAT / 4); idx += kBlock) dst[idx] = src[idx];
+    for (int idx = threadIdx.x; idx < g * N * (GN_FEAT / 4); idx += kBlock) dst[idx] = ld4(src + 4 * idx);
     for (int idx = threadIdx.x; idx < g * te * N; idx += kBlock) {
       const int s = idx / (te * N), r = idx - s * te * N;
       s_H[idx] = Gr.H[((size_t)(b0 + s) * E + e0) * N + r];
@@ -423,14 +450,14 @@ __global__ __launch_bounds__(kBlock) void agg_gather_kernel(GatherTable T, int B
       acc[2] = fmaf(hv, v[2], acc[2]);
       acc[3] = fmaf(hv, v[3], acc[3]);
     }
-    reinterpret_cast<f32x4*>(Gr.eo + ((size_t)(b0 + s) * E + e0 + e) * GN_FEAT)[d] = acc;
+    st4(reinterpret_cast<TS*>(Gr.eo) + ((size_t)(b0 + s) * E + e0 + e) * GN_FEAT + 4 * d, acc);
   }
 }
 
 // Pairwise graph: eo[(i,j)] = ori_i + ori_j (2 ori_i on the diagonal), H never materialised.
-template <bool SYM>
-__global__ __launch_bounds__(kBlock) void agg_gather_pairwise_kernel(const float* __restrict__ ori,
-                                                                     float* __restrict__ eo, int N,
+template <bool SYM, typename TS>
+__global__ __launch_bounds__(kBlock) void agg_gather_pairwise_kernel(const TS* __restrict__ ori,
+                                                                     TS* __restrict__ eo, int N,
                                                                      long long total4) {
   const int E = SYM ? gn_pair_count(N) : N * N;
   for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total4;
@@ -445,10 +472,10 @@ __global__ __launch_bounds__(kBlock) void agg_gather_pairwise_kernel(const float
       i = e / N;
       j = e - i * N;
     }
-    const f32x4* o4 = reinterpret_cast<const f32x4*>(ori + (size_t)b * N * GN_FEAT) + d;
-    const f32x4 a = o4[i * 16], c = o4[j * 16];
+    const TS* o4 = ori + (size_t)b * N * GN_FEAT + 4 * d;
+    const f32x4 a = ld4(o4 + (size_t)i * GN_FEAT), c = ld4(o4 + (size_t)j * GN_FEAT);
     f32x4 r = {a[0] + c[0], a[1] + c[1], a[2] + c[2], a[3] + c[3]};
-    reinterpret_cast<f32x4*>(eo)[idx] = r;
+    st4(eo + 4 * idx, r);
   }
 }
 
@@ -456,6 +483,7 @@ struct ScatterTable {
   gn_scatter_group_t g[GN_MAX_GROUPS];
 };
 // blockIdx.y = group; LDS sized for the largest E of the launch
+template <typename TS>
 __global__ __launch_bounds__(kBlock) void agg_scatter_kernel(ScatterTable T, int B, int N, int G, int Emax,
                                                              float fN) {
   extern __shared__ __align__(16) float lds[];
@@ -466,9 +494,9 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_kernel(ScatterTable T, int
   float* s_feat = lds;                              // g x E x 64
   float* s_H = lds + (size_t)G * Emax * GN_FEAT;    // g x E x N
   {
-    const f32x4* src = reinterpret_cast<const f32x4*>(Gr.feat + (size_t)b0 * E * GN_FEAT);
+    const TS* src = reinterpret_cast<const TS*>(Gr.feat) + (size_t)b0 * E * GN_FEAT;
     f32x4* dst = reinterpret_cast<f32x4*>(s_feat);
-    for (int idx = threadIdx.x; idx < g * E * (GN_FEAT / 4); idx += kBlock) dst[idx] = src[idx];
+    for (int idx = threadIdx.x; idx < g * E * (GN_FEAT / 4); idx += kBlock) dst[idx] = ld4(src + 4 * idx);
     const float* hs = Gr.H + (size_t)b0 * E * N;
     for (int idx = threadIdx.x; idx < g * E * N; idx += kBlock) s_H[idx] = hs[idx];
   }
@@ -490,21 +518,21 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_kernel(ScatterTable T, int
         acc[3] = fmaf(hv, v[3], acc[3]);
       }
     } else {
-      acc = reinterpret_cast<const f32x4*>(Gr.ori + ((size_t)(b0 + s) * N + n) * GN_FEAT)[d - 16];
+      acc = ld4(reinterpret_cast<const TS*>(Gr.ori) + ((size_t)(b0 + s) * N + n) * GN_FEAT + 4 * (d - 16));
     }
     f32x4 r = {acc[0] / fN, acc[1] / fN, acc[2] / fN, acc[3] / fN};
-    reinterpret_cast<f32x4*>(Gr.out + ((size_t)(b0 + s) * N + n) * 2 * GN_FEAT)[d] = r;
+    st4(reinterpret_cast<TS*>(Gr.out) + ((size_t)(b0 + s) * N + n) * 2 * GN_FEAT + 4 * d, r);
   }
 }
 
 // Large-E / pairwise scatter straight from global memory (feat rows are 256-byte lines; every
 // row is read by exactly two nodes in the pairwise case, so the second read is an L2 hit).
 // MODE 0: general H (large E); 1: pairwise, E = N*N ordered edges; 2: pairwise, E = N(N+1)/2 pair sums
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const float* __restrict__ feat,
+template <int MODE, typename TS>
+__global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const TS* __restrict__ feat,
                                                                     const float* __restrict__ H,
-                                                                    const float* __restrict__ ori,
-                                                                    float* __restrict__ out, int N, int E,
+                                                                    const TS* __restrict__ ori,
+                                                                    TS* __restrict__ out, int N, int E,
                                                                     long long total4, float fN) {
   for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total4;
        idx += (long long)gridDim.x * kBlock) {
@@ -514,11 +542,11 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const float*
     f32x4 acc;
     if (d < 16) {
       acc = {0.f, 0.f, 0.f, 0.f};
-      const f32x4* f4 = reinterpret_cast<const f32x4*>(feat + (size_t)b * E * GN_FEAT) + d;
+      const TS* f4 = feat + (size_t)b * E * GN_FEAT + 4 * d;
       if (MODE == 2) {
         // every pair {n,j} once: the pair row already holds both ordered edges (and the self-loop's 2)
         for (int j = 0; j < N; ++j) {
-          const f32x4 v = f4[(size_t)gn_pair_index(n, j, N) * 16];
+          const f32x4 v = ld4(f4 + (size_t)gn_pair_index(n, j, N) * GN_FEAT);
           acc[0] += v[0];
           acc[1] += v[1];
           acc[2] += v[2];
@@ -527,8 +555,8 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const float*
       } else if (MODE == 1) {
         // (n,n) counts twice (H = 2 on self-loops); fp32 tolerance makes the edge order immaterial
         for (int j = 0; j < N; ++j) {
-          const f32x4 v = f4[(size_t)(n * N + j) * 16];
-          const f32x4 w = f4[(size_t)(j * N + n) * 16];
+          const f32x4 v = ld4(f4 + (size_t)(n * N + j) * GN_FEAT);
+          const f32x4 w = ld4(f4 + (size_t)(j * N + n) * GN_FEAT);
           acc[0] += v[0] + w[0];
           acc[1] += v[1] + w[1];
           acc[2] += v[2] + w[2];
@@ -539,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const float*
         for (int e = 0; e < E; ++e) {
           const float hv = hcol[(size_t)e * N];
           if (hv != 0.f) {
-            const f32x4 v = f4[(size_t)e * 16];
+            const f32x4 v = ld4(f4 + (size_t)e * GN_FEAT);
             acc[0] = fmaf(hv, v[0], acc[0]);
             acc[1] = fmaf(hv, v[1], acc[1]);
             acc[2] = fmaf(hv, v[2], acc[2]);
@@ -548,10 +576,10 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const float*
         }
       }
     } else {
-      acc = reinterpret_cast<const f32x4*>(ori + ((size_t)b * N + n) * GN_FEAT)[d - 16];
+      acc = ld4(ori + ((size_t)b * N + n) * GN_FEAT + 4 * (d - 16));
     }
     f32x4 r = {acc[0] / fN, acc[1] / fN, acc[2] / fN, acc[3] / fN};
-    reinterpret_cast<f32x4*>(out)[idx] = r;
+    st4(out + 4 * idx, r);
   }
 }
 
@@ -715,7 +743,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) 
 
 }  // namespace
 
-extern "C" int gn_abi_version(void) { return 25; }
+extern "C" int gn_abi_version(void) { return 26; }
 
 extern "C" const char* gn_strerror(int code) {
   switch (code) {
@@ -739,9 +767,9 @@ extern "C" int gn_affinity_f32(const float* f, float* corr, int B, int N, int D,
   if (fused <= kLdsBudget) {
     ScaleList sl{};
     sl.n = 0;
-    gn_allow_big_lds(affinity_topk_kernel);
-    hipLaunchKernelGGL(affinity_topk_kernel, dim3(B), dim3(kBlock), fused, (hipStream_t)stream, f, corr, sl, N, D,
-                       gn_block_extras_t{});
+    gn_allow_big_lds(affinity_topk_kernel<float>);
+    hipLaunchKernelGGL(affinity_topk_kernel<float>, dim3(B), dim3(kBlock), fused, (hipStream_t)stream, f, corr, sl, N,
+                       D, gn_block_extras_t{});
   } else {
     const size_t lds = (size_t)(16 + 64) * (D + 4) * sizeof(float);
     gn_allow_big_lds(affinity_banded_kernel);
@@ -795,9 +823,11 @@ extern "C" int gn_listall_incidence_f32(const float* corr, float* H, int B, int 
   return gn_check_launch();
 }
 
-extern "C" int gn_affinity_topk_f32(const float* f, float* corr, float* const* H_list, const int* k_list, int n_scales,
-                                    int B, int N, int D, const gn_block_extras_t* extras, gn_stream_t stream) {
+template <typename TS>
+static int affinity_topk_launch(const TS* f, float* corr, float* const* H_list, const int* k_list, int n_scales, int B,
+                                int N, int D, const gn_block_extras_t* extras, hipStream_t stream) {
   const bool embed = extras != nullptr && extras->x_raw != nullptr;
+  if (embed && sizeof(TS) != sizeof(float)) return GN_ERR_SHAPE;   // the embedding front-end is fp32 only
   if (!embed) {
     GN_REQUIRE_PTR(f);
     GN_REQUIRE_ALIGNED(f);
@@ -819,30 +849,55 @@ extern "C" int gn_affinity_topk_f32(const float* f, float* corr, float* const* H
     if (ex.f_out != nullptr && (!gn_aligned16(ex.f_out) || ex.f_out_ld < D || (ex.f_out_ld & 3))) return GN_ERR_ALIGN;
     sl.H_cat = ex.H_cat;
   }
-  gn_allow_big_lds(affinity_topk_kernel);
-  hipLaunchKernelGGL(affinity_topk_kernel, dim3(B), dim3(kBlock), fused, (hipStream_t)stream, f, corr, sl, N, D, ex);
+  gn_allow_big_lds(affinity_topk_kernel<TS>);
+  hipLaunchKernelGGL(affinity_topk_kernel<TS>, dim3(B), dim3(kBlock), fused, stream, f, corr, sl, N, D, ex);
   return gn_check_launch();
 }
-
-static int check_groups(const void* groups, int n) {
-  if (groups == nullptr) return GN_ERR_NULL;
-  if (n < 1 || n > GN_MAX_GROUPS) return GN_ERR_SHAPE;
-  return GN_OK;
+extern "C" int gn_affinity_topk_f32(const float* f, float* corr, float* const* H_list, const int* k_list, int n_scales,
+                                    int B, int N, int D, const gn_block_extras_t* extras, gn_stream_t stream) {
+  return affinity_topk_launch<float>(f, corr, H_list, k_list, n_scales, B, N, D, extras, (hipStream_t)stream);
+}
+extern "C" int gn_affinity_topk_bf16(const void* f, float* corr, float* const* H_list, const int* k_list, int n_scales,
+                                     int B, int N, int D, const gn_block_extras_t* extras, gn_stream_t stream) {
+  return affinity_topk_launch<__bf16>(reinterpret_cast<const __bf16*>(f), corr, H_list, k_list, n_scales, B, N, D,
+                                      extras, (hipStream_t)stream);
 }
 
-extern "C" int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, gn_stream_t stream) {
+template <typename TS>
+static int node2edge_launch(const gn_n2e_group_t* groups, int n_groups, int B, int N, hipStream_t s) {
   int rc = check_groups(groups, n_groups);
   if (rc != GN_OK) return rc;
   if (B <= 0 || N <= 0) return GN_ERR_SHAPE;
-  GroupTable<gn_n2e_group_t> T{};
+  WaveTable<gn_n2e_group_t> T{};
+  PairTable P{};
   long long waves = 0;
+  int pair_wgs = 0;
+  size_t lds = 0;
   for (int g = 0; g < n_groups; ++g) {
     const gn_n2e_group_t& G = groups[g];
     if (!G.xp || !G.pq || !G.w2 || !G.b2 || !G.edges) return GN_ERR_NULL;
     if (G.E <= 0) return GN_ERR_SHAPE;
-    if (!gn_aligned16(G.xp) || !gn_aligned16(G.edges)) return GN_ERR_ALIGN;
+    if (!gn_aligned16(G.xp) || !gn_aligned16(G.pq) || !gn_aligned16(G.edges)) return GN_ERR_ALIGN;
     if (G.H == nullptr) {
       if ((long long)G.E != (G.sym ? (long long)gn_pair_count(N) : (long long)N * N)) return GN_ERR_SHAPE;
+      // pairwise groups: scenes per workgroup so that the staged rows stay <= 32 KiB; edge bands when one
+      // scene alone has many more edges than a workgroup should walk
+      const size_t per_scene = (size_t)N * (GN_FEAT + GN_FEAT + 1) * sizeof(float);
+      const size_t fixed = (3 * kBlock + 32) * sizeof(float);
+      if (per_scene + fixed > 158 * 1024 || N > 32767) return GN_ERR_LDS;   // one workgroup may take the CU's 160 KiB
+      int SG = 1;
+      while (SG < 8 && (size_t)(2 * SG) * per_scene <= 32 * 1024 && (B + 2 * SG - 1) / (2 * SG) >= 512) SG *= 2;
+      const long long edges_per_wg = (long long)SG * G.E;
+      int bands = 1;
+      while (bands < 64 && edges_per_wg / (bands * 2) >= 2048 && (long long)((B + SG - 1) / SG) * bands < 2048)
+        bands *= 2;
+      P.g[P.n] = G;
+      P.SG[P.n] = SG;
+      P.bands[P.n] = bands;
+      P.first_wg[P.n] = pair_wgs;
+      pair_wgs += ((B + SG - 1) / SG) * bands;
+      ++P.n;
+      lds = lds > (size_t)SG * per_scene + fixed ? lds : (size_t)SG * per_scene + fixed;
       continue;
     }
     if (G.sym) return GN_ERR_SHAPE;  // the symmetric form exists for the pairwise graph only
@@ -852,42 +907,30 @@ extern "C" int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int 
     ++T.n;
   }
   T.first[T.n] = waves;
-  hipStream_t s = (hipStream_t)stream;
-  // pairwise groups: scenes per workgroup so that the staged rows stay <= 32 KiB; edge bands when one
-  // scene alone has many more edges than a workgroup should walk
-  for (int g = 0; g < n_groups; ++g) {
-    const gn_n2e_group_t& G = groups[g];
-    if (G.H != nullptr) continue;
-    const size_t per_scene = (size_t)N * (GN_FEAT + GN_FEAT + 1) * sizeof(float);
-    const size_t fixed = (3 * kBlock + 32) * sizeof(float);
-    if (per_scene + fixed > 158 * 1024 || N > 32767) return GN_ERR_LDS;   // one workgroup may take the CU's 160 KiB
-    int SG = 1;
-    while (SG < 8 && (size_t)(2 * SG) * per_scene <= 32 * 1024 && (B + 2 * SG - 1) / (2 * SG) >= 512) SG *= 2;
-    const long long edges_per_wg = (long long)SG * G.E;
-    int bands = 1;
-    while (bands < 64 && edges_per_wg / (bands * 2) >= 2048 && (long long)((B + SG - 1) / SG) * bands < 2048)
-      bands *= 2;
-    const size_t lds = (size_t)SG * per_scene + fixed;
-    gn_allow_big_lds(node2edge_pairwise_kernel);
-    hipLaunchKernelGGL(node2edge_pairwise_kernel, dim3(((B + SG - 1) / SG) * bands), dim3(kBlock), lds, s, G, B, N, SG,
-                       bands);
-  }
+  P.first_wg[P.n] = pair_wgs;
   if (T.n > 0) {
-    const size_t lds = (size_t)(kBlock / 64) * 3 * N * sizeof(float);
-    if (lds > kLdsBudget) return GN_ERR_LDS;
-    const long long grid = (waves + 3) / 4;
-    if (grid > 0x7fffffffLL) return GN_ERR_SHAPE;
-    gn_allow_big_lds(node2edge_kernel);
-    hipLaunchKernelGGL(node2edge_kernel, dim3((unsigned)grid), dim3(kBlock), lds, s, T, N);
+    const size_t l = (size_t)(kBlock / 64) * 3 * N * sizeof(float);
+    if (l > kLdsBudget) return GN_ERR_LDS;
+    lds = lds > l ? lds : l;
   }
+  const long long grid = pair_wgs + (waves + 3) / 4;
+  if (grid > 0x7fffffffLL) return GN_ERR_SHAPE;
+  gn_allow_big_lds(node2edge_kernel<TS>);
+  hipLaunchKernelGGL(node2edge_kernel<TS>, dim3((unsigned)grid), dim3(kBlock), lds, s, T, P, B, N);
   return gn_check_launch();
 }
+extern "C" int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, gn_stream_t stream) {
+  return node2edge_launch<float>(groups, n_groups, B, N, (hipStream_t)stream);
+}
+extern "C" int gn_node2edge_bf16(const gn_n2e_group_t* groups, int n_groups, int B, int N, gn_stream_t stream) {
+  return node2edge_launch<__bf16>(groups, n_groups, B, N, (hipStream_t)stream);
+}
 
-extern "C" int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, int B, int N, gn_stream_t stream) {
+template <typename TS>
+static int gather_launch(const gn_gather_group_t* groups, int n_groups, int B, int N, hipStream_t s) {
   int rc = check_groups(groups, n_groups);
   if (rc != GN_OK) return rc;
   if (B <= 0 || N <= 0) return GN_ERR_SHAPE;
-  hipStream_t s = (hipStream_t)stream;
   GatherTable T{};
   int nh = 0, Emax = 0;
   for (int g = 0; g < n_groups; ++g) {
@@ -908,10 +951,12 @@ extern "C" int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, 
     if (G.H != nullptr) continue;
     const long long total4 = (long long)B * G.E * 16;
     const dim3 grid(capped_grid(total4, kBlock * 4));
+    const TS* ori = reinterpret_cast<const TS*>(G.ori);
+    TS* eo = reinterpret_cast<TS*>(G.eo);
     if (G.sym)
-      hipLaunchKernelGGL((agg_gather_pairwise_kernel<true>), grid, dim3(kBlock), 0, s, G.ori, G.eo, N, total4);
+      hipLaunchKernelGGL((agg_gather_pairwise_kernel<true, TS>), grid, dim3(kBlock), 0, s, ori, eo, N, total4);
     else
-      hipLaunchKernelGGL((agg_gather_pairwise_kernel<false>), grid, dim3(kBlock), 0, s, G.ori, G.eo, N, total4);
+      hipLaunchKernelGGL((agg_gather_pairwise_kernel<false, TS>), grid, dim3(kBlock), 0, s, ori, eo, N, total4);
   }
   if (nh > 0) {
     const size_t ori_b = (size_t)N * GN_FEAT * sizeof(float);
@@ -927,19 +972,24 @@ extern "C" int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, 
       if (TE < 1) return GN_ERR_LDS;
     }
     const size_t lds = (size_t)G * ori_b + (size_t)G * TE * N * sizeof(float);
-    gn_allow_big_lds(agg_gather_kernel);
-    hipLaunchKernelGGL(agg_gather_kernel, dim3((B + G - 1) / G, (Emax + TE - 1) / TE, nh), dim3(kBlock), lds, s, T, B,
-                       N, G, TE);
+    gn_allow_big_lds(agg_gather_kernel<TS>);
+    hipLaunchKernelGGL(agg_gather_kernel<TS>, dim3((B + G - 1) / G, (Emax + TE - 1) / TE, nh), dim3(kBlock), lds, s, T,
+                       B, N, G, TE);
   }
   return gn_check_launch();
 }
+extern "C" int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, int B, int N, gn_stream_t stream) {
+  return gather_launch<float>(groups, n_groups, B, N, (hipStream_t)stream);
+}
+extern "C" int gn_agg_gather_bf16(const gn_gather_group_t* groups, int n_groups, int B, int N, gn_stream_t stream) {
+  return gather_launch<__bf16>(groups, n_groups, B, N, (hipStream_t)stream);
+}
 
-extern "C" int gn_agg_scatter_f32(const gn_scatter_group_t* groups, int n_groups, int B, int N, float divisor,
-                                  gn_stream_t stream) {
+template <typename TS>
+static int scatter_launch(const gn_scatter_group_t* groups, int n_groups, int B, int N, float divisor, hipStream_t s) {
   int rc = check_groups(groups, n_groups);
   if (rc != GN_OK) return rc;
   if (B <= 0 || N <= 0 || !(divisor != 0.f)) return GN_ERR_SHAPE;
-  hipStream_t s = (hipStream_t)stream;
   const long long total4 = (long long)B * N * 32;
   ScatterTable T{};
   int nh = 0, Emax = 0;
@@ -954,15 +1004,18 @@ extern "C" int gn_agg_scatter_f32(const gn_scatter_group_t* groups, int n_groups
   }
   for (int g = 0; g < n_groups; ++g) {
     const gn_scatter_group_t& G = groups[g];
+    const TS* feat = reinterpret_cast<const TS*>(G.feat);
+    const TS* ori = reinterpret_cast<const TS*>(G.ori);
+    TS* out = reinterpret_cast<TS*>(G.out);
     if (G.H == nullptr && G.sym) {
-      hipLaunchKernelGGL((agg_scatter_direct_kernel<2>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
-                         G.feat, G.H, G.ori, G.out, N, G.E, total4, divisor);
+      hipLaunchKernelGGL((agg_scatter_direct_kernel<2, TS>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
+                         feat, G.H, ori, out, N, G.E, total4, divisor);
     } else if (G.H == nullptr) {
-      hipLaunchKernelGGL((agg_scatter_direct_kernel<1>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
-                         G.feat, G.H, G.ori, G.out, N, G.E, total4, divisor);
+      hipLaunchKernelGGL((agg_scatter_direct_kernel<1, TS>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
+                         feat, G.H, ori, out, N, G.E, total4, divisor);
     } else if ((size_t)G.E * (GN_FEAT + N) * sizeof(float) > kLdsBudget / 2) {
-      hipLaunchKernelGGL((agg_scatter_direct_kernel<0>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
-                         G.feat, G.H, G.ori, G.out, N, G.E, total4, divisor);
+      hipLaunchKernelGGL((agg_scatter_direct_kernel<0, TS>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
+                         feat, G.H, ori, out, N, G.E, total4, divisor);
     } else {
       T.g[nh++] = G;
       Emax = G.E > Emax ? G.E : Emax;
@@ -973,11 +1026,19 @@ extern "C" int gn_agg_scatter_f32(const gn_scatter_group_t* groups, int n_groups
     int G = 1;
     while (G < 16 && (size_t)(2 * G) * per_scene <= 24 * 1024 && (long long)((B + 2 * G - 1) / (2 * G)) * nh >= 1024)
       G *= 2;
-    gn_allow_big_lds(agg_scatter_kernel);
-    hipLaunchKernelGGL(agg_scatter_kernel, dim3((B + G - 1) / G, nh), dim3(kBlock), (size_t)G * per_scene, s, T, B, N,
-                       G, Emax, divisor);
+    gn_allow_big_lds(agg_scatter_kernel<TS>);
+    hipLaunchKernelGGL(agg_scatter_kernel<TS>, dim3((B + G - 1) / G, nh), dim3(kBlock), (size_t)G * per_scene, s, T, B,
+                       N, G, Emax, divisor);
   }
   return gn_check_launch();
+}
+extern "C" int gn_agg_scatter_f32(const gn_scatter_group_t* groups, int n_groups, int B, int N, float divisor,
+                                  gn_stream_t stream) {
+  return scatter_launch<float>(groups, n_groups, B, N, divisor, (hipStream_t)stream);
+}
+extern "C" int gn_agg_scatter_bf16(const gn_scatter_group_t* groups, int n_groups, int B, int N, float divisor,
+                                   gn_stream_t stream) {
+  return scatter_launch<__bf16>(groups, n_groups, B, N, divisor, (hipStream_t)stream);
 }
 
 __global__ void counter_add_kernel(unsigned long long* ctr, unsigned long long add) {

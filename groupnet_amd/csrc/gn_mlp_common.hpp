@@ -1,0 +1,330 @@
+// Device helpers shared by the MFMA kernels of the GroupNet MS-HGNN path (gn_mlp_mfma.hip: fp32 matrix cores;
+// gn_mlp_bf16.hip: bf16 matrix cores): row-block addressing, the register layout of a 32-row block, fused
+// gather / scatter prologues, the Gumbel-softmax epilogue and host-side argument checks.
+#pragma once
+#include <stdlib.h>
+
+#include "gn_common.hpp"
+
+namespace {
+
+constexpr int kTileFloats = 32 * 32;  // one packed 32x32 weight tile
+
+// feature held by register r of a lane in half h, inside a 32-feature tile
+__device__ __forceinline__ constexpr int feat_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// fp32 -> three bf16 parts (round to nearest even each time; the remainders are exact in fp32)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
+  p1 = (__bf16)x;
+  const float r1 = x - (float)p1;
+  p2 = (__bf16)r1;
+  p3 = (__bf16)(r1 - (float)p2);
+}
+
+// ---- storage types -----------------------------------------------------------------------------
+// Activations live in HBM as fp32 (the *_f32 entry points) or bf16 (the *_bf16 twins, BASELINE config 4);
+// registers always hold fp32.  Four consecutive features are one access: 16 bytes (fp32) or 8 bytes (bf16).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const __bf16* p) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(__bf16* p, const f32x4& v) {
+  const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
+
+// ---- register-resident building blocks -----------------------------------------------------
+template <int IT, typename T>
+__device__ __forceinline__ void load_rows(const T* __restrict__ X, int ld, int row, int h, f32x16 (&a)[IT]) {
+  const T* p = X + (size_t)row * ld + 4 * h;
+#pragma unroll
+  for (int t = 0; t < IT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = ld4(p + 32 * t + 8 * q);
+      a[t][4 * q + 0] = v[0];
+      a[t][4 * q + 1] = v[1];
+      a[t][4 * q + 2] = v[2];
+      a[t][4 * q + 3] = v[3];
+    }
+}
+
+template <int OT, typename T>
+__device__ __forceinline__ void store_rows(T* __restrict__ Y, int ld, int row, int h, bool live,
+                                           const f32x16 (&a)[OT]) {
+  if (!live) return;
+  T* p = Y + (size_t)row * ld + 4 * h;
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {a[o][4 * q + 0], a[o][4 * q + 1], a[o][4 * q + 2], a[o][4 * q + 3]};
+      st4(p + 32 * o + 8 * q, v);
+    }
+}
+
+// The 16 bias values a lane needs for one 32-feature output tile (its accumulator's initial value).
+__device__ __forceinline__ f32x16 load_bias_tile(const float* __restrict__ bias_tile, int h) {
+  f32x16 b;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(bias_tile + 8 * q + 4 * h);
+    b[4 * q + 0] = v[0];
+    b[4 * q + 1] = v[1];
+    b[4 * q + 2] = v[2];
+    b[4 * q + 3] = v[3];
+  }
+  return b;
+}
+
+__device__ __forceinline__ void relu16(f32x16& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f);
+}
+
+struct RowBlock {
+  int lane, h, row, row_ld;  // row = this lane's row; row_ld = clamped row used for loads
+  bool live;
+};
+__device__ __forceinline__ RowBlock row_block(int rows, int block_index) {
+  RowBlock rb;
+  rb.lane = threadIdx.x & 63;
+  rb.h = rb.lane >> 5;
+  rb.row = block_index * 32 + (rb.lane & 31);
+  rb.live = rb.row < rows;
+  rb.row_ld = rb.live ? rb.row : rows - 1;
+  return rb;
+}
+__device__ __forceinline__ int wave_id() { return gn_uniform((int)(threadIdx.x >> 6)); }
+
+// ---- group tables (kernel arguments, by value) -------------------------------------------------
+// blockIdx -> (group, workgroup inside the group).  Groups with equal work use blockIdx.y; ragged ones a
+// prefix table in workgroup units, so a workgroup never straddles two groups and the lookup is scalar.
+template <typename G>
+struct GroupTable {
+  G g[GN_MAX_GROUPS];
+  int first_wg[GN_MAX_GROUPS + 1];
+  int n;
+};
+template <typename G>
+__device__ __forceinline__ int find_group(const GroupTable<G>& t, int wg) {
+  int g = 0;
+  while (g + 1 < t.n && wg >= t.first_wg[g + 1]) ++g;
+  return gn_uniform(g);
+}
+
+// Gumbel softmax over the K logits of a row whose features are split over its two lanes (j, h=0/1):
+// d[r] = softmax_f((lg_f + g_f) / tau), g = -log(eps - log(u + eps))   (MS_HGNN_batch.py:446-473).
+__device__ __forceinline__ void gumbel_softmax_row(const f32x16& lg, const float (&u)[8], int K, float tau, int h,
+                                                   float (&d)[8]) {
+  const float eps = 1e-10f;  // MS_HGNN_batch.py:446
+  float y[8];
+  float m = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float g = -logf(eps - logf(u[r] + eps));
+    y[r] = (lg[r] + g) / tau;
+    if (feat_of(r, h) < K) m = fmaxf(m, y[r]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, GN_WAVE));
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    d[r] = (feat_of(r, h) < K) ? expf(y[r] - m) : 0.f;
+    s += d[r];
+  }
+  s += __shfl_xor(s, 32, GN_WAVE);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) d[r] = d[r] / s;
+}
+
+// uniforms of this lane's features for ordered row `orow`: from U, or from the Philox stream
+__device__ __forceinline__ void fetch_uniforms(const float* __restrict__ U, unsigned long long base,
+                                               unsigned long long seed, long long orow, int K, int h, float (&u)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int f = feat_of(r, h);
+    if (f >= K)
+      u[r] = 0.5f;
+    else if (U != nullptr)
+      u[r] = U[(size_t)orow * K + f];
+    else
+      u[r] = gn_philox_uniform_at(base + (unsigned long long)orow * K + f, seed);
+  }
+}
+
+// The 16 pre-activation values lane (j,h) needs of hidden tile t of type k for ONE node: A row + offset.
+struct PreTile {
+  f32x4 v[4];
+};
+template <typename T>
+__device__ __forceinline__ PreTile load_pre(const T* __restrict__ arow, int h) {
+  PreTile p;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p.v[q] = ld4(arow + 8 * q + 4 * h);
+  return p;
+}
+
+// ---- A5 typed MLP: feat = sum_k ef[:,k] * (W2k relu(W1k eo + b1k) + b2k) --------------------------
+// W = for each type k: [W1k (128x64) | W2k (64x128)] packed (64 steps per type); b1 (K,128); b2 (K,64).
+// Work shape, chosen per group by the launcher (block-uniform): `wpr` waves share one 32-row block,
+// wave w of them takes types w, w+wpr, ... and the partial sums meet in LDS.
+//   wpr = 1 : every wave owns a row block and walks all K types (no LDS);
+//   wpr = 2 : the pairwise module (K = 6 -> 3 types per wave): twice as many, half as long work units,
+//             which is what lets the chip's 1024 SIMDs finish together (one 6-type unit is ~47 us);
+//   wpr = 4 : groups with fewer row blocks than SIMDs (the hyper modules at B*N rows): 4x shorter
+//             critical path.
+// Input rows of the typed MLP formed on the fly (fused gather): lane (j,h) accumulates its 32 features
+// of row r = b*E + e from the member nodes' ori rows.
+template <typename T>
+__device__ __forceinline__ void add_row(const T* __restrict__ src, float w, int h, f32x16 (&a)[2]) {
+  const T* p = src + 4 * h;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = ld4(p + 32 * t + 8 * q);
+      a[t][4 * q + 0] = fmaf(w, v[0], a[t][4 * q + 0]);
+      a[t][4 * q + 1] = fmaf(w, v[1], a[t][4 * q + 1]);
+      a[t][4 * q + 2] = fmaf(w, v[2], a[t][4 * q + 2]);
+      a[t][4 * q + 3] = fmaf(w, v[3], a[t][4 * q + 3]);
+    }
+}
+template <typename T = float>
+__device__ __forceinline__ void gather_rows(const gn_agg_group_t& G, int row, int h, f32x16 (&a)[2]) {
+  const int E = G.E, N = G.N;
+  const int b = row / E, e = row - b * E;
+  const T* ob = reinterpret_cast<const T*>(G.ori) + (size_t)b * N * GN_FEAT;
+  if (G.H == nullptr) {
+    int i, j;
+    if (G.sym) {
+      gn_pair_decode(e, N, i, j);
+    } else {
+      i = e / N;
+      j = e - i * N;
+    }
+    load_rows<2>(ob, GN_FEAT, i, h, a);           // ori_i
+    add_row(ob + (size_t)j * GN_FEAT, 1.f, h, a);  // + ori_j  (2 ori_i on the diagonal)
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[t][r] = 0.f;
+    const float* hrow = G.H + (size_t)row * N;
+    for (int n = 0; n < N; ++n) {
+      const float hv = hrow[n];
+      if (hv != 0.f) add_row(ob + (size_t)n * GN_FEAT, hv, h, a);
+    }
+  }
+}
+
+__device__ __forceinline__ void relu_scale16(f32x16& a, float w) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f) * w;
+}
+
+// Input rows of the MLP: read from x, or — fused scatter, IT == 4 — formed on the fly as
+// cat(sum_e H[b,e,n] feat[b,e], ori[b,n]) / divisor  (edge_aggregation.forward + edge2node's / N).
+template <int IT, typename T = float>
+__device__ __forceinline__ void mlp2_rows(const gn_mlp2_group_t& G, int row, int h, int N, float divisor,
+                                          f32x16 (&in)[IT]) {
+  if (G.x != nullptr) {
+    load_rows<IT>(reinterpret_cast<const T*>(G.x), IT * 32, row, h, in);
+    return;
+  }
+  if constexpr (IT == 4) {
+    const int E = G.E;
+    const int b = row / N, n = row - b * N;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const T* fb = reinterpret_cast<const T*>(G.feat) + (size_t)b * E * GN_FEAT;
+    if (G.H != nullptr) {
+      const float* hcol = G.H + (size_t)b * E * N + n;
+      for (int e = 0; e < E; ++e) {
+        const float hv = hcol[(size_t)e * N];
+        if (hv != 0.f) add_row(fb + (size_t)e * GN_FEAT, hv, h, acc);
+      }
+    } else if (G.sym) {
+      for (int j = 0; j < N; ++j) add_row(fb + (size_t)gn_pair_index(n, j, N) * GN_FEAT, 1.f, h, acc);
+    } else {
+      for (int j = 0; j < N; ++j) {
+        add_row(fb + (size_t)(n * N + j) * GN_FEAT, 1.f, h, acc);
+        add_row(fb + (size_t)(j * N + n) * GN_FEAT, 1.f, h, acc);
+      }
+    }
+    f32x16 o[2];
+    load_rows<2>(reinterpret_cast<const T*>(G.ori), GN_FEAT, row, h, o);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        in[t][r] = acc[t][r] / divisor;
+        in[2 + t][r] = o[t][r] / divisor;
+      }
+  }
+}
+
+// one output tile (16 registers of this lane) -> y, honouring dout / ldy that are not multiples of 4
+template <typename T>
+__device__ __forceinline__ void store_out_tile(T* __restrict__ y, int row, int ldy, int dout, int o, int h,
+                                               const f32x16& acc) {
+  T* p = y + (size_t)row * ldy;
+  if (((dout | ldy) & 3) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = 32 * o + 8 * q + 4 * h;
+      if (f < dout) {
+        f32x4 v = {acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        st4(p + f, v);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = 32 * o + feat_of(r, h);
+      if (f < dout) st1(p + f, acc[r]);
+    }
+  }
+}
+
+constexpr int kTypeSteps = 64;
+struct AggGroup {
+  gn_agg_group_t a;
+  int wpr;
+  int stage;   // pair form, wpr == 1: the workgroup stages the per-node pre-activations of its scenes in LDS
+};
+constexpr int kStagePitch = 128 + 4;                 // floats per staged node row (one type)
+constexpr int kStageFloats = 4 * 32 * 64;            // the LDS the kernel owns (shared with the wpr > 1 partial sums)
+constexpr int kStageMaxNodes = kStageFloats / kStagePitch;
+constexpr int kStageLoads = (kStageMaxNodes * 32 + 255) / 256;
+
+inline int row_grid(int rows) { return (rows + 127) / 128; }  // 4 waves x 32 rows per block
+
+inline int check_groups(const void* groups, int n) {
+  if (groups == nullptr) return GN_ERR_NULL;
+  if (n < 1 || n > GN_MAX_GROUPS) return GN_ERR_SHAPE;
+  return GN_OK;
+}
+#define GN_CHECK(expr)            \
+  do {                            \
+    const int rc_ = (expr);       \
+    if (rc_ != GN_OK) return rc_; \
+  } while (0)
+inline int need(const void* p, bool aligned) {
+  if (p == nullptr) return GN_ERR_NULL;
+  if (aligned && !gn_aligned16(p)) return GN_ERR_ALIGN;
+  return GN_OK;
+}
+
+}  // namespace

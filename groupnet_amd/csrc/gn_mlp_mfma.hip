@@ -23,14 +23,11 @@
 // GEMMs only by summation order (~1e-7 relative).
 #include <stdlib.h>
 
-#include "gn_common.hpp"
+#include "gn_mlp_common.hpp"
+#include "gn_mlp_bf16.hpp"
 
 namespace {
 
-constexpr int kTileFloats = 32 * 32;  // one packed 32x32 weight tile
-
-// feature held by register r of a lane in half h, inside a 32-feature tile
-__device__ __forceinline__ constexpr int feat_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ---- packing -------------------------------------------------------------------------------
 // Wp[(((o*IT + t)*4 + q)*64 + lane)*4 + c] = W[32o + (lane&31)][32t + 8q + 4(lane>>5) + c]
@@ -72,16 +69,8 @@ __global__ __launch_bounds__(256) void pack_segments_kernel(const gn_pack_seg_t*
   }
 }
 
-// fp32 -> three bf16 parts (round to nearest even each time; the remainders are exact in fp32)
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
-  p1 = (__bf16)x;
-  const float r1 = x - (float)p1;
-  p2 = (__bf16)r1;
-  p3 = (__bf16)(r1 - (float)p2);
-}
-__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ packed, __bf16* __restrict__ out,
-                                                           int n_tiles) {
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ packed, __bf16* __restrict__ out,
+                                                         int n_tiles, int parts) {
   // one thread per (tile, half, lane, j)
   const long long total = (long long)n_tiles * 2 * 64 * 8;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -90,56 +79,15 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     const float x = packed[tile * kTileFloats + (((j >> 2) + 2 * half) * 64 + lane) * 4 + (j & 3)];
     __bf16 p1, p2, p3;
     split3(x, p1, p2, p3);
-    __bf16* o = out + ((tile * 2 + half) * 3 * 64 + lane) * 8 + j;
+    __bf16* o = out + ((tile * 2 + half) * parts * 64 + lane) * 8 + j;
     o[0] = p1;
-    o[64 * 8] = p2;
-    o[2 * 64 * 8] = p3;
+    if (parts == 3) {
+      o[64 * 8] = p2;
+      o[2 * 64 * 8] = p3;
+    }
   }
 }
 
-// ---- register-resident building blocks -----------------------------------------------------
-template <int IT>
-__device__ __forceinline__ void load_rows(const float* __restrict__ X, int ld, int row, int h, f32x16 (&a)[IT]) {
-  const float* p = X + (size_t)row * ld + 4 * h;
-#pragma unroll
-  for (int t = 0; t < IT; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p + 32 * t + 8 * q);
-      a[t][4 * q + 0] = v[0];
-      a[t][4 * q + 1] = v[1];
-      a[t][4 * q + 2] = v[2];
-      a[t][4 * q + 3] = v[3];
-    }
-}
-
-template <int OT>
-__device__ __forceinline__ void store_rows(float* __restrict__ Y, int ld, int row, int h, bool live,
-                                           const f32x16 (&a)[OT]) {
-  if (!live) return;
-  float* p = Y + (size_t)row * ld + 4 * h;
-#pragma unroll
-  for (int o = 0; o < OT; ++o)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 v = {a[o][4 * q + 0], a[o][4 * q + 1], a[o][4 * q + 2], a[o][4 * q + 3]};
-      *reinterpret_cast<f32x4*>(p + 32 * o + 8 * q) = v;
-    }
-}
-
-// The 16 bias values a lane needs for one 32-feature output tile (its accumulator's initial value).
-__device__ __forceinline__ f32x16 load_bias_tile(const float* __restrict__ bias_tile, int h) {
-  f32x16 b;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(bias_tile + 8 * q + 4 * h);
-    b[4 * q + 0] = v[0];
-    b[4 * q + 1] = v[1];
-    b[4 * q + 2] = v[2];
-    b[4 * q + 3] = v[3];
-  }
-  return b;
-}
 
 #ifndef GN_RING_DEPTH
 #define GN_RING_DEPTH 8
@@ -191,10 +139,6 @@ __device__ __forceinline__ void mma_tile(const f32x4* __restrict__ cur, const f3
   }
 }
 
-__device__ __forceinline__ void relu16(f32x16& a) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f);
-}
 
 // State of a wave walking the weight / bias streams of a chain of layers laid out back to back.
 struct Chain {
@@ -230,36 +174,6 @@ __device__ __forceinline__ void chain_linear(Chain& c, const f32x16 (&in)[IT], f
   }
 }
 
-struct RowBlock {
-  int lane, h, row, row_ld;  // row = this lane's row; row_ld = clamped row used for loads
-  bool live;
-};
-__device__ __forceinline__ RowBlock row_block(int rows, int block_index) {
-  RowBlock rb;
-  rb.lane = threadIdx.x & 63;
-  rb.h = rb.lane >> 5;
-  rb.row = block_index * 32 + (rb.lane & 31);
-  rb.live = rb.row < rows;
-  rb.row_ld = rb.live ? rb.row : rows - 1;
-  return rb;
-}
-__device__ __forceinline__ int wave_id() { return gn_uniform((int)(threadIdx.x >> 6)); }
-
-// ---- group tables (kernel arguments, by value) -------------------------------------------------
-// blockIdx -> (group, workgroup inside the group).  Groups with equal work use blockIdx.y; ragged ones a
-// prefix table in workgroup units, so a workgroup never straddles two groups and the lookup is scalar.
-template <typename G>
-struct GroupTable {
-  G g[GN_MAX_GROUPS];
-  int first_wg[GN_MAX_GROUPS + 1];
-  int n;
-};
-template <typename G>
-__device__ __forceinline__ int find_group(const GroupTable<G>& t, int wg) {
-  int g = 0;
-  while (g + 1 < t.n && wg >= t.first_wg[g + 1]) ++g;
-  return gn_uniform(g);
-}
 
 // ---- A3 first half: x' = MLP(64->256->64)(x); pq = x' Wpq^T + bpq -----------------------------
 // W = [W0 (256x64) | W1 (64x256) | Wpq (64x64)] packed, bias = [b0 | b1 | bpq].  blockIdx.y = group.
@@ -283,45 +197,6 @@ __global__ __launch_bounds__(256) void node_mlp_kernel(GroupTable<gn_node_group_
 // ---- A4: z = MLP(64->128->64); [dist|fac] heads; gumbel softmax; sigmoid ------------------------
 // W = [Wi0 (128x64) | Wi1 (64x128) | Wd0 (256x64) | Wd1 (32x256)] packed, bias likewise.
 
-// Gumbel softmax over the K logits of a row whose features are split over its two lanes (j, h=0/1):
-// d[r] = softmax_f((lg_f + g_f) / tau), g = -log(eps - log(u + eps))   (MS_HGNN_batch.py:446-473).
-__device__ __forceinline__ void gumbel_softmax_row(const f32x16& lg, const float (&u)[8], int K, float tau, int h,
-                                                   float (&d)[8]) {
-  const float eps = 1e-10f;  // MS_HGNN_batch.py:446
-  float y[8];
-  float m = -INFINITY;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const float g = -logf(eps - logf(u[r] + eps));
-    y[r] = (lg[r] + g) / tau;
-    if (feat_of(r, h) < K) m = fmaxf(m, y[r]);
-  }
-  m = fmaxf(m, __shfl_xor(m, 32, GN_WAVE));
-  float s = 0.f;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    d[r] = (feat_of(r, h) < K) ? expf(y[r] - m) : 0.f;
-    s += d[r];
-  }
-  s += __shfl_xor(s, 32, GN_WAVE);
-#pragma unroll
-  for (int r = 0; r < 8; ++r) d[r] = d[r] / s;
-}
-
-// uniforms of this lane's features for ordered row `orow`: from U, or from the Philox stream
-__device__ __forceinline__ void fetch_uniforms(const float* __restrict__ U, unsigned long long base,
-                                               unsigned long long seed, long long orow, int K, int h, float (&u)[8]) {
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int f = feat_of(r, h);
-    if (f >= K)
-      u[r] = 0.5f;
-    else if (U != nullptr)
-      u[r] = U[(size_t)orow * K + f];
-    else
-      u[r] = gn_philox_uniform_at(base + (unsigned long long)orow * K + f, seed);
-  }
-}
 
 __global__ __launch_bounds__(256, 2) void edge_mlp_gumbel_kernel(GroupTable<gn_edge_group_t> T, float tau,
                                                               unsigned long long seed,
@@ -363,100 +238,6 @@ __global__ __launch_bounds__(256, 2) void edge_mlp_gumbel_kernel(GroupTable<gn_e
   //   A: T0 T1 S0 T2 S1 T3 S2 S3        (T = Wi0 tile, S = the two Wi1 slices over it: 8 steps each)
   //   B: T0 T1 S0 T2 S1 ... T7 S6 S7    (T = Wd0 tile: 8 steps, S = the Wd1 slice over it: 4 steps)
   // followed by 8 steps of padding, because the ring always reads 8 steps ahead.
-  if (G.Wx3 != nullptr) {
-    // ---- the same two layer pairs with fp32-accurate products on the bf16 cores (x = x1+x2+x3, six part-products
-    // per k = 16 sub-step), hidden-tile by hidden-tile exactly as below: tile t of the first layer (4 sub-steps),
-    // ReLU, its bf16 parts, then its slice of the second layer (4 sub-steps for z's two tiles, 2 for the logits
-    // tile).  80 sub-steps per row block, walked linearly through the three-part image of the hidden-tile-major
-    // weight stream; a 4-sub-step register ring is refilled in place (24 MFMAs ahead).
-    const int lane = rb.lane, h = rb.h;
-    const float* bi0 = G.bias;
-    const float* bi1 = G.bias + 128;
-    const float* bd0 = G.bias + 192;
-    const float* bd1 = G.bias + 448;
-    const f32x4* Wx = reinterpret_cast<const f32x4*>(G.Wx3) + lane;     // sub-step s, part p: (s*3 + p)*64
-    f32x4 wq[12];
-#pragma unroll
-    for (int u = 0; u < 12; ++u) wq[u] = Wx[u * 64];
-    constexpr int kSub = 80;
-    auto sub = [&](int s, const bf16x8 (&x)[3], f32x16& acc) {
-      const int u = (s & 3) * 3;
-      const bf16x8 w1 = __builtin_bit_cast(bf16x8, wq[u + 0]);
-      const bf16x8 w2 = __builtin_bit_cast(bf16x8, wq[u + 1]);
-      const bf16x8 w3 = __builtin_bit_cast(bf16x8, wq[u + 2]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x[0], acc, 0, 0, 0);
-      const int sn = s + 4 < kSub ? s + 4 : s + 4 - kSub;     // (past the end: any valid piece)
-      const f32x4* src = Wx + (size_t)sn * 3 * 64;
-      wq[u + 0] = src[0];
-      wq[u + 1] = src[64];
-      wq[u + 2] = src[128];
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto parts = [&](const f32x16& v, bf16x8 (&x)[2][3]) {
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          __bf16 a, b, c;
-          split3(v[8 * hf + jj], a, b, c);
-          x[hf][0][jj] = a;
-          x[hf][1][jj] = b;
-          x[hf][2][jj] = c;
-        }
-    };
-    bf16x8 xi[2][2][3];      // parts of the current layer pair's input (edges, then z)
-    parts(in[0], xi[0]);
-    parts(in[1], xi[1]);
-    z[0] = load_bias_tile(bi1, h);
-    z[1] = load_bias_tile(bi1 + 32, h);
-    lg[0] = load_bias_tile(bd1, h);
-    // ---- pair A: 4 hidden tiles x (4 + 4) sub-steps ----
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x16 hid = load_bias_tile(bi0 + 32 * t, h);
-      sub(8 * t + 0, xi[0][0], hid);
-      sub(8 * t + 1, xi[0][1], hid);
-      sub(8 * t + 2, xi[1][0], hid);
-      sub(8 * t + 3, xi[1][1], hid);
-      relu16(hid);
-      if (G.keep_z1 != nullptr) {
-        f32x16 tmp[1] = {hid};
-        store_rows<1>(G.keep_z1 + 32 * t, 128, rb.row, h, rb.live, tmp);
-      }
-      bf16x8 xh[2][3];
-      parts(hid, xh);
-      sub(8 * t + 4, xh[0], z[0]);
-      sub(8 * t + 5, xh[1], z[0]);
-      sub(8 * t + 6, xh[0], z[1]);
-      sub(8 * t + 7, xh[1], z[1]);
-    }
-    if (G.keep_z != nullptr) store_rows<2>(G.keep_z, GN_FEAT, rb.row, h, rb.live, z);
-    parts(z[0], xi[0]);
-    parts(z[1], xi[1]);
-    // ---- pair B: 8 hidden tiles x (4 + 2) sub-steps ----
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      f32x16 hid = load_bias_tile(bd0 + 32 * t, h);
-      sub(32 + 6 * t + 0, xi[0][0], hid);
-      sub(32 + 6 * t + 1, xi[0][1], hid);
-      sub(32 + 6 * t + 2, xi[1][0], hid);
-      sub(32 + 6 * t + 3, xi[1][1], hid);
-      relu16(hid);
-      if (G.keep_dh1 != nullptr) {
-        f32x16 tmp[1] = {hid};
-        store_rows<1>(G.keep_dh1 + 32 * t, 256, rb.row, h, rb.live, tmp);
-      }
-      bf16x8 xh[2][3];
-      parts(hid, xh);
-      sub(32 + 6 * t + 4, xh[0], lg[0]);
-      sub(32 + 6 * t + 5, xh[1], lg[0]);
-    }
-  } else
   {
     const int lane = rb.lane, h = rb.h;
     const float* bi0 = G.bias;
@@ -603,82 +384,7 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const float* __restric
   }
 }
 
-// The 16 pre-activation values lane (j,h) needs of hidden tile t of type k for ONE node: A row + offset.
-struct PreTile {
-  f32x4 v[4];
-};
-__device__ __forceinline__ PreTile load_pre(const float* __restrict__ arow, int h) {
-  PreTile p;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) p.v[q] = *reinterpret_cast<const f32x4*>(arow + 8 * q + 4 * h);
-  return p;
-}
 
-// ---- A5 typed MLP: feat = sum_k ef[:,k] * (W2k relu(W1k eo + b1k) + b2k) --------------------------
-// W = for each type k: [W1k (128x64) | W2k (64x128)] packed (64 steps per type); b1 (K,128); b2 (K,64).
-// Work shape, chosen per group by the launcher (block-uniform): `wpr` waves share one 32-row block,
-// wave w of them takes types w, w+wpr, ... and the partial sums meet in LDS.
-//   wpr = 1 : every wave owns a row block and walks all K types (no LDS);
-//   wpr = 2 : the pairwise module (K = 6 -> 3 types per wave): twice as many, half as long work units,
-//             which is what lets the chip's 1024 SIMDs finish together (one 6-type unit is ~47 us);
-//   wpr = 4 : groups with fewer row blocks than SIMDs (the hyper modules at B*N rows): 4x shorter
-//             critical path.
-// Input rows of the typed MLP formed on the fly (fused gather): lane (j,h) accumulates its 32 features
-// of row r = b*E + e from the member nodes' ori rows.
-__device__ __forceinline__ void add_row(const float* __restrict__ src, float w, int h, f32x16 (&a)[2]) {
-  const float* p = src + 4 * h;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p + 32 * t + 8 * q);
-      a[t][4 * q + 0] = fmaf(w, v[0], a[t][4 * q + 0]);
-      a[t][4 * q + 1] = fmaf(w, v[1], a[t][4 * q + 1]);
-      a[t][4 * q + 2] = fmaf(w, v[2], a[t][4 * q + 2]);
-      a[t][4 * q + 3] = fmaf(w, v[3], a[t][4 * q + 3]);
-    }
-}
-__device__ __forceinline__ void gather_rows(const gn_agg_group_t& G, int row, int h, f32x16 (&a)[2]) {
-  const int E = G.E, N = G.N;
-  const int b = row / E, e = row - b * E;
-  const float* ob = G.ori + (size_t)b * N * GN_FEAT;
-  if (G.H == nullptr) {
-    int i, j;
-    if (G.sym) {
-      gn_pair_decode(e, N, i, j);
-    } else {
-      i = e / N;
-      j = e - i * N;
-    }
-    load_rows<2>(ob, GN_FEAT, i, h, a);           // ori_i
-    add_row(ob + (size_t)j * GN_FEAT, 1.f, h, a);  // + ori_j  (2 ori_i on the diagonal)
-  } else {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a[t][r] = 0.f;
-    const float* hrow = G.H + (size_t)row * N;
-    for (int n = 0; n < N; ++n) {
-      const float hv = hrow[n];
-      if (hv != 0.f) add_row(ob + (size_t)n * GN_FEAT, hv, h, a);
-    }
-  }
-}
-
-constexpr int kTypeSteps = 64;
-struct AggGroup {
-  gn_agg_group_t a;
-  int wpr;
-  int stage;   // pair form, wpr == 1: the workgroup stages the per-node pre-activations of its scenes in LDS
-};
-constexpr int kStagePitch = 128 + 4;                 // floats per staged node row (one type)
-constexpr int kStageFloats = 4 * 32 * 64;            // the LDS the kernel owns (shared with the wpr > 1 partial sums)
-constexpr int kStageMaxNodes = kStageFloats / kStagePitch;
-constexpr int kStageLoads = (kStageMaxNodes * 32 + 255) / 256;
-__device__ __forceinline__ void relu_scale16(f32x16& a, float w) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f) * w;
-}
 __global__ __launch_bounds__(256, 2) void agg_mlp_kernel(GroupTable<AggGroup> T) {
   __shared__ float part[4][32][64];  // wpr > 1 only: [wave][register 0..31][lane]
   const int gi = find_group(T, blockIdx.x);
@@ -705,130 +411,7 @@ __global__ __launch_bounds__(256, 2) void agg_mlp_kernel(GroupTable<AggGroup> T)
   const float* b2 = G.b2;
 
   int k = sub;
-  if (G.A != nullptr && staged && G.W2x3 != nullptr) {
-    // ---- pair form, staged: every lane needs the pre-activations of ITS two nodes — 16-byte pieces scattered
-    // over up to 32 rows per load, which makes the texture-address path, not the matrix cores, the limiter.
-    // The 4 row blocks of this workgroup touch at most 3 scenes, i.e. a short run of consecutive node rows: the
-    // workgroup copies that run (one type at a time, coalesced, prefetched in registers under the previous
-    // type's MFMAs) into LDS, and the lanes pick their rows from there.
-    float* stage = &part[0][0][0];
-    const int N = G.N, P = G.E;
-    const int r0 = wg * 128, r1 = min(rows - 1, r0 + 127);
-    const int node0 = (r0 / P) * N;
-    const int nodes = (r1 / P + 1) * N - node0;
-    const size_t ldA = (size_t)K * 128;
-    const f32x4* Ag = reinterpret_cast<const f32x4*>(G.A + (size_t)node0 * ldA);
-    const int total4 = nodes * 32;                      // float4 pieces per type
-    f32x4 pre[kStageLoads];
-    auto fetch = [&](int kk) {
-#pragma unroll
-      for (int it = 0; it < kStageLoads; ++it) {
-        const int idx = min((int)threadIdx.x + it * 256, total4 - 1);
-        pre[it] = Ag[(size_t)(idx >> 5) * (ldA / 4) + kk * 32 + (idx & 31)];
-      }
-    };
-    auto commit = [&]() {
-#pragma unroll
-      for (int it = 0; it < kStageLoads; ++it) {
-        const int idx = (int)threadIdx.x + it * 256;
-        if (idx < total4) *reinterpret_cast<f32x4*>(stage + (idx >> 5) * kStagePitch + (idx & 31) * 4) = pre[it];
-      }
-    };
-    int i = 0, j = 0;
-    {
-      const int b = rb.row_ld / P, p = rb.row_ld - b * P;
-      gn_pair_decode(p, N, i, j);
-      i += b * N - node0;
-      j += b * N - node0;
-    }
-    const float* Si = stage + i * kStagePitch;
-    const float* Sj = stage + j * kStagePitch;
-    // bf16x6 route: this lane's pointer into the three-part image; tile (k,t,o), half hf, part p sits at
-    // ((((k*8 + t*2 + o)*2 + hf)*3 + p)*64 + lane) 16-byte pieces
-    const f32x4* Wx = reinterpret_cast<const f32x4*>(G.W2x3) + lane;
-    f32x4 wq[12];
-#pragma unroll
-    for (int u = 0; u < 12; ++u) wq[u] = Wx[u * 64];
-    fetch(0);
-    commit();
-    __syncthreads();
-    PreTile pa = load_pre(Si, h), pb = load_pre(Sj, h);
-    float efk = efrow[0];
-    float b2f0 = h == 0 ? b2[lane & 31] : 0.f;
-    float b2f1 = h == 0 ? b2[32 + (lane & 31)] : 0.f;
-#pragma unroll 1
-    for (k = 0; k < K; ++k) {
-      const int kc = k + 1 < K ? k + 1 : k;
-      fetch(kc);                                        // next type's rows: in flight during this type's MFMAs
-      const float efk_next = efrow[kc];
-      const float b2n0 = h == 0 ? b2[kc * 64 + (lane & 31)] : 0.f;
-      const float b2n1 = h == 0 ? b2[kc * 64 + 32 + (lane & 31)] : 0.f;
-      const float efb = h == 0 ? efk : 0.f;
-      out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f0, efb, out[0], 0, 0, 0);
-      out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f1, efb, out[1], 0, 0, 0);
-      {
-        // ---- fp32-accurate products on the bf16 cores: x = x1 + x2 + x3 (bf16 parts), weights pre-split;
-        //      w.x ~ w3x1 + w2x2 + w1x3 + w2x1 + w1x2 + w1x1 (small terms first), six k=16 MFMAs per half tile.
-        //      Weight parts of tile (k, t, o), half hf: 3 x 16 bytes per lane, fetched one hidden tile ahead.
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          f32x16 hid1;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx)
-              hid1[4 * q + cidx] = fmaxf(pa.v[q][cidx] + pb.v[q][cidx], 0.f) * efk;
-          if (t < 3) {
-            pa = load_pre(Si + 32 * (t + 1), h);
-            pb = load_pre(Sj + 32 * (t + 1), h);
-          }
-          // wq holds this hidden tile's 4 x 3 weight pieces; each triple is refilled with the NEXT tile's right
-          // after its six MFMAs are issued (24 MFMAs of run-ahead)
-          const int tn = t < 3 ? t + 1 : 0, kn = t < 3 ? k : kc;
-          const f32x4* src = Wx + ((size_t)(kn * 8 + tn * 2) * 6) * 64;
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            bf16x8 x1, x2, x3;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-              __bf16 a, b, c;
-              split3(hid1[8 * hf + jj], a, b, c);
-              x1[jj] = a;
-              x2[jj] = b;
-              x3[jj] = c;
-            }
-#pragma unroll
-            for (int o = 0; o < 2; ++o) {
-              const int u = (o * 2 + hf) * 3;
-              const bf16x8 w1 = __builtin_bit_cast(bf16x8, wq[u + 0]);
-              const bf16x8 w2 = __builtin_bit_cast(bf16x8, wq[u + 1]);
-              const bf16x8 w3 = __builtin_bit_cast(bf16x8, wq[u + 2]);
-              f32x16& acc = out[o];
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x3, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x1, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x2, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc, 0, 0, 0);
-              wq[u + 0] = src[(u + 0) * 64];
-              wq[u + 1] = src[(u + 1) * 64];
-              wq[u + 2] = src[(u + 2) * 64];
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        }
-      }
-      __syncthreads();                                  // every wave has read type k's rows
-      commit();
-      __syncthreads();
-      pa = load_pre(Si, h);
-      pb = load_pre(Sj, h);
-      efk = efk_next;
-      b2f0 = b2n0;
-      b2f1 = b2n1;
-    }
-    if (!any_rows) return;
-  } else if (G.A != nullptr && staged) {
+  if (G.A != nullptr && staged) {
     // ---- pair form, staged: every lane needs the pre-activations of ITS two nodes — 16-byte pieces scattered
     // over up to 32 rows per load, which makes the texture-address path, not the matrix cores, the limiter.
     // The 4 row blocks of this workgroup touch at most 3 scenes, i.e. a short run of consecutive node rows: the
@@ -972,98 +555,6 @@ __global__ __launch_bounds__(256, 2) void agg_mlp_kernel(GroupTable<AggGroup> T)
         k = kn;
       }
     }
-  } else if (G.W12x3 != nullptr && k < K && any_rows) {
-    // ---- two-layer form with fp32-accurate products on the bf16 cores.  Hidden-tile by hidden-tile: tile o of
-    // layer 1 (4 sub-steps: in tile t, half hf), ReLU * ef_k, its three bf16 parts, then its contribution to
-    // both output tiles (4 sub-steps) — only one hidden tile is ever live.  A sub-step = three 16-byte weight
-    // pieces per lane and six MFMAs; the pieces run through a 4-sub-step ring refilled in place (24 MFMAs ahead),
-    // in exactly the order gn_split_bf16x3_f32 of the hidden-tile-major image lays them out.
-    f32x16 in[2];
-    if (G.eo != nullptr)
-      load_rows<2>(G.eo, GN_FEAT, rb.row_ld, h, in);
-    else
-      gather_rows(G, rb.row_ld, h, in);
-    bf16x8 xin[2][2][3];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          __bf16 a, b, c;
-          split3(in[t][8 * hf + jj], a, b, c);
-          xin[t][hf][0][jj] = a;
-          xin[t][hf][1][jj] = b;
-          xin[t][hf][2][jj] = c;
-        }
-    const f32x4* Wx = reinterpret_cast<const f32x4*>(G.W12x3) + lane;   // sub-step s of type k: ((k*32 + s)*3 + part)*64
-    f32x4 wq[12];
-#pragma unroll
-    for (int u = 0; u < 12; ++u) wq[u] = Wx[((size_t)k * 32 * 3 + u) * 64];
-    f32x16 bnext = load_bias_tile(b1 + k * 128, h);
-    float efk = efrow[k];
-    float b2f0 = h == 0 ? b2[k * 64 + (lane & 31)] : 0.f;
-    float b2f1 = h == 0 ? b2[k * 64 + 32 + (lane & 31)] : 0.f;
-#pragma unroll 1
-    while (k < K) {
-      const int kn = k + wpr;
-      const int kc = kn < K ? kn : k;
-      const f32x4* cur = Wx + (size_t)k * 32 * 3 * 64;
-      const f32x4* nxt = Wx + (size_t)kc * 32 * 3 * 64;
-      const float efk_next = efrow[kc];
-      const float b2n0 = h == 0 ? b2[kc * 64 + (lane & 31)] : 0.f;
-      const float b2n1 = h == 0 ? b2[kc * 64 + 32 + (lane & 31)] : 0.f;
-      const float efb = h == 0 ? efk : 0.f;
-      out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f0, efb, out[0], 0, 0, 0);
-      out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2f1, efb, out[1], 0, 0, 0);
-      // one sub-step: six part-products into acc, then refill the ring slot with the sub-step 4 ahead
-      auto sub = [&](int s, const bf16x8 (&x)[3], f32x16& acc) {
-        const int u = (s & 3) * 3;
-        const bf16x8 w1 = __builtin_bit_cast(bf16x8, wq[u + 0]);
-        const bf16x8 w2 = __builtin_bit_cast(bf16x8, wq[u + 1]);
-        const bf16x8 w3 = __builtin_bit_cast(bf16x8, wq[u + 2]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x[0], acc, 0, 0, 0);
-        const f32x4* src = s + 4 < 32 ? cur + (size_t)(s + 4) * 3 * 64 : nxt + (size_t)(s + 4 - 32) * 3 * 64;
-        wq[u + 0] = src[0];
-        wq[u + 1] = src[64];
-        wq[u + 2] = src[128];
-        __builtin_amdgcn_sched_barrier(0);
-      };
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        f32x16 hid = bnext;
-        bnext = load_bias_tile(o < 3 ? b1 + k * 128 + 32 * (o + 1) : b1 + kc * 128, h);
-        sub(8 * o + 0, xin[0][0], hid);
-        sub(8 * o + 1, xin[0][1], hid);
-        sub(8 * o + 2, xin[1][0], hid);
-        sub(8 * o + 3, xin[1][1], hid);
-        relu_scale16(hid, efk);
-        bf16x8 xh[2][3];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) {
-            __bf16 a, b, c;
-            split3(hid[8 * hf + jj], a, b, c);
-            xh[hf][0][jj] = a;
-            xh[hf][1][jj] = b;
-            xh[hf][2][jj] = c;
-          }
-        sub(8 * o + 4, xh[0], out[0]);
-        sub(8 * o + 5, xh[1], out[0]);
-        sub(8 * o + 6, xh[0], out[1]);
-        sub(8 * o + 7, xh[1], out[1]);
-      }
-      efk = efk_next;
-      b2f0 = b2n0;
-      b2f1 = b2n1;
-      k = kn;
-    }
   } else if (k < K && any_rows) {
     f32x16 in[2], hid[4];
     if (G.eo != nullptr)
@@ -1141,71 +632,6 @@ __global__ __launch_bounds__(256, 2) void agg_mlp_kernel(GroupTable<AggGroup> T)
 // ---- A6 / generic: y = W1 relu(W0 x + b0) + b1 ----------------------------------------------------
 // W = [W0 (dh x din) | W1 (dout x dh)] packed; bias = [b0 (dh) | b1 padded to a multiple of 32].
 
-// Input rows of the MLP: read from x, or — fused scatter, IT == 4 — formed on the fly as
-// cat(sum_e H[b,e,n] feat[b,e], ori[b,n]) / divisor  (edge_aggregation.forward + edge2node's / N).
-template <int IT>
-__device__ __forceinline__ void mlp2_rows(const gn_mlp2_group_t& G, int row, int h, int N, float divisor,
-                                          f32x16 (&in)[IT]) {
-  if (G.x != nullptr) {
-    load_rows<IT>(G.x, IT * 32, row, h, in);
-    return;
-  }
-  if constexpr (IT == 4) {
-    const int E = G.E;
-    const int b = row / N, n = row - b * N;
-    f32x16 acc[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const float* fb = G.feat + (size_t)b * E * GN_FEAT;
-    if (G.H != nullptr) {
-      const float* hcol = G.H + (size_t)b * E * N + n;
-      for (int e = 0; e < E; ++e) {
-        const float hv = hcol[(size_t)e * N];
-        if (hv != 0.f) add_row(fb + (size_t)e * GN_FEAT, hv, h, acc);
-      }
-    } else if (G.sym) {
-      for (int j = 0; j < N; ++j) add_row(fb + (size_t)gn_pair_index(n, j, N) * GN_FEAT, 1.f, h, acc);
-    } else {
-      for (int j = 0; j < N; ++j) {
-        add_row(fb + (size_t)(n * N + j) * GN_FEAT, 1.f, h, acc);
-        add_row(fb + (size_t)(j * N + n) * GN_FEAT, 1.f, h, acc);
-      }
-    }
-    f32x16 o[2];
-    load_rows<2>(G.ori, GN_FEAT, row, h, o);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        in[t][r] = acc[t][r] / divisor;
-        in[2 + t][r] = o[t][r] / divisor;
-      }
-  }
-}
-
-// one output tile (16 registers of this lane) -> y, honouring dout / ldy that are not multiples of 4
-__device__ __forceinline__ void store_out_tile(float* __restrict__ y, int row, int ldy, int dout, int o, int h,
-                                               const f32x16& acc) {
-  float* p = y + (size_t)row * ldy;
-  if (((dout | ldy) & 3) == 0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int f = 32 * o + 8 * q + 4 * h;
-      if (f < dout) {
-        f32x4 v = {acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        *reinterpret_cast<f32x4*>(p + f) = v;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = 32 * o + feat_of(r, h);
-      if (f < dout) p[f] = acc[r];
-    }
-  }
-}
 
 // Whole form: every wave owns a row block, output tiles streamed.  blockIdx.y = group.
 template <int IT, int HT>
@@ -1368,23 +794,6 @@ __global__ __launch_bounds__(256) void node_mlp_split_kernel(GroupTable<gn_node_
   }
 }
 
-inline int row_grid(int rows) { return (rows + 127) / 128; }  // 4 waves x 32 rows per block
-
-inline int check_groups(const void* groups, int n) {
-  if (groups == nullptr) return GN_ERR_NULL;
-  if (n < 1 || n > GN_MAX_GROUPS) return GN_ERR_SHAPE;
-  return GN_OK;
-}
-#define GN_CHECK(expr)            \
-  do {                            \
-    const int rc_ = (expr);       \
-    if (rc_ != GN_OK) return rc_; \
-  } while (0)
-inline int need(const void* p, bool aligned) {
-  if (p == nullptr) return GN_ERR_NULL;
-  if (aligned && !gn_aligned16(p)) return GN_ERR_ALIGN;
-  return GN_OK;
-}
 
 }  // namespace
 
@@ -1407,14 +816,14 @@ extern "C" int gn_pack_linear_f32(const float* W, float* Wp, int out_features, i
   return gn_check_launch();
 }
 
-extern "C" int gn_split_bf16x3_f32(const float* packed, void* out, int n_tiles, gn_stream_t stream) {
+extern "C" int gn_split_bf16_f32(const float* packed, void* out, int n_tiles, int parts, gn_stream_t stream) {
   GN_REQUIRE_PTR(packed);
   GN_REQUIRE_PTR(out);
-  if (n_tiles < 1) return GN_ERR_SHAPE;
+  if (n_tiles < 1 || (parts != 1 && parts != 3)) return GN_ERR_SHAPE;
   GN_REQUIRE_ALIGNED(out);
   const long long total = (long long)n_tiles * 1024;
-  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)),
-                     dim3(256), 0, (hipStream_t)stream, packed, reinterpret_cast<__bf16*>(out), n_tiles);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)),
+                     dim3(256), 0, (hipStream_t)stream, packed, reinterpret_cast<__bf16*>(out), n_tiles, parts);
   return gn_check_launch();
 }
 
@@ -1427,15 +836,57 @@ extern "C" int gn_pack_segments_f32(const gn_pack_seg_t* segs_dev, int n_segs, i
   return gn_check_launch();
 }
 
+// How many groups of a launch carry the bf16-core image: all (returns 1), none (0), or a mix (-1, an error).
+template <typename G, typename F>
+static int x_mode(const G* groups, int n, F has) {
+  int cnt = 0;
+  for (int g = 0; g < n; ++g) cnt += has(groups[g]) ? 1 : 0;
+  return cnt == 0 ? 0 : (cnt == n ? 1 : -1);
+}
+
+// ---- node stage ----------------------------------------------------------------------------------------------
+template <int P, typename T>
+static int node_stage_launch(const gn_node_group_t* groups, int n_groups, int rows, hipStream_t s) {
+  NodeTable Tb{};
+  Tb.n = n_groups;
+  Tb.rows = rows;
+  Tb.blocks32 = (rows + 31) / 32;
+  Tb.chain_units = n_groups * Tb.blocks32;
+  int a_units = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_node_group_t& G = groups[g];
+    const void* ptrs[] = {G.x, G.Wx, G.bias, G.xp, G.pq};
+    for (const void* p : ptrs) GN_CHECK(need(p, true));
+    if (P == 1 && G.hid_out != nullptr) return GN_ERR_SHAPE;   // the twins are forward-only
+    Tb.a_first[g] = a_units;
+    if (G.A != nullptr) {
+      GN_CHECK(need(G.WAx, true));
+      GN_CHECK(need(G.bA, true));
+      GN_CHECK(need(G.A, true));
+      if (G.KA < 1 || G.KA > GN_MAX_TYPES) return GN_ERR_SHAPE;
+      a_units += Tb.blocks32 * ((4 * G.KA + kATiles - 1) / kATiles);
+    }
+    Tb.g[g] = G;
+  }
+  Tb.a_first[n_groups] = a_units;
+  Tb.total_units = Tb.chain_units + a_units;
+  hipLaunchKernelGGL((node_stage_kernel<P, T>), dim3((Tb.total_units + 3) / 4), dim3(256), 0, s, Tb);
+  return gn_check_launch();
+}
+
 extern "C" int gn_node_mlp_f32(const gn_node_group_t* groups, int n_groups, int rows, gn_stream_t stream) {
   GN_CHECK(check_groups(groups, n_groups));
   if (rows <= 0) return GN_ERR_SHAPE;
+  const int xm = x_mode(groups, n_groups, [](const gn_node_group_t& G) { return G.Wx != nullptr; });
+  if (xm < 0) return GN_ERR_SHAPE;
+  if (xm == 1) return node_stage_launch<3, float>(groups, n_groups, rows, (hipStream_t)stream);
   GroupTable<gn_node_group_t> T{};
   T.n = n_groups;
   for (int g = 0; g < n_groups; ++g) {
     const gn_node_group_t& G = groups[g];
     const void* ptrs[] = {G.x, G.W, G.bias, G.xp, G.pq};
     for (const void* p : ptrs) GN_CHECK(need(p, true));
+    if (G.A != nullptr) return GN_ERR_SHAPE;   // the fused per-node layer exists on the bf16-core path only
     T.g[g] = G;
   }
   const int blocks32 = (rows + 31) / 32;
@@ -1446,40 +897,70 @@ extern "C" int gn_node_mlp_f32(const gn_node_group_t* groups, int n_groups, int 
   return gn_check_launch();
 }
 
-extern "C" int gn_edge_mlp_gumbel_f32(const gn_edge_group_t* groups, int n_groups, float tau,
-                                      unsigned long long seed, const unsigned long long* offset_dev,
-                                      gn_stream_t stream) {
+extern "C" int gn_node_mlp_bf16(const gn_node_group_t* groups, int n_groups, int rows, gn_stream_t stream) {
+  GN_CHECK(check_groups(groups, n_groups));
+  if (rows <= 0) return GN_ERR_SHAPE;
+  return node_stage_launch<1, __bf16>(groups, n_groups, rows, (hipStream_t)stream);
+}
+
+// ---- edge MLP --------------------------------------------------------------------------------------------------
+static int edge_launch(const gn_edge_group_t* groups, int n_groups, float tau, unsigned long long seed,
+                       const unsigned long long* offset_dev, hipStream_t stream, bool twin) {
   GN_CHECK(check_groups(groups, n_groups));
   if (!(tau > 0.f)) return GN_ERR_SHAPE;
+  const int xm = x_mode(groups, n_groups, [](const gn_edge_group_t& G) { return G.Wx != nullptr; });
+  if (xm < 0 || (twin && xm != 1)) return GN_ERR_SHAPE;
   GroupTable<gn_edge_group_t> T{};
   T.n = n_groups;
   int wg = 0;
   for (int g = 0; g < n_groups; ++g) {
     const gn_edge_group_t& G = groups[g];
     GN_CHECK(need(G.edges, true));
-    GN_CHECK(need(G.W, true));
+    GN_CHECK(need(xm ? G.Wx : (const void*)G.W, true));
     GN_CHECK(need(G.bias, true));
     GN_CHECK(need(G.edge_feat, false));
     if (G.sym_N == 0) GN_CHECK(need(G.dist, false));
     if (G.rows <= 0 || G.K < 1 || G.K > 15 || G.sym_N < 0) return GN_ERR_SHAPE;
     if (G.sym_N > 0 && G.rows % gn_pair_count(G.sym_N) != 0) return GN_ERR_SHAPE;
+    if (twin && (G.keep_z1 || G.keep_z || G.keep_dh1 || G.keep_lgf)) return GN_ERR_SHAPE;
     T.g[g] = G;
     T.first_wg[g] = wg;
     wg += row_grid(G.rows);
   }
   T.first_wg[n_groups] = wg;
-  hipLaunchKernelGGL(edge_mlp_gumbel_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, T, tau, seed, offset_dev);
+  if (twin)
+    hipLaunchKernelGGL((edge_x_kernel<1, __bf16>), dim3(wg), dim3(256), 0, stream, T, tau, seed, offset_dev);
+  else if (xm)
+    hipLaunchKernelGGL((edge_x_kernel<3, float>), dim3(wg), dim3(256), 0, stream, T, tau, seed, offset_dev);
+  else
+    hipLaunchKernelGGL(edge_mlp_gumbel_kernel, dim3(wg), dim3(256), 0, stream, T, tau, seed, offset_dev);
   return gn_check_launch();
 }
+extern "C" int gn_edge_mlp_gumbel_f32(const gn_edge_group_t* groups, int n_groups, float tau,
+                                      unsigned long long seed, const unsigned long long* offset_dev,
+                                      gn_stream_t stream) {
+  return edge_launch(groups, n_groups, tau, seed, offset_dev, (hipStream_t)stream, false);
+}
+extern "C" int gn_edge_mlp_gumbel_bf16(const gn_edge_group_t* groups, int n_groups, float tau,
+                                       unsigned long long seed, const unsigned long long* offset_dev,
+                                       gn_stream_t stream) {
+  return edge_launch(groups, n_groups, tau, seed, offset_dev, (hipStream_t)stream, true);
+}
 
-extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream) {
+// ---- typed aggregation MLP ---------------------------------------------------------------------------------------
+static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t stream, bool twin) {
   GN_CHECK(check_groups(groups, n_groups));
+  const int xm = x_mode(groups, n_groups, [](const gn_agg_group_t& G) {
+    return (G.A != nullptr ? G.W2x : G.W12x) != nullptr;
+  });
+  if (xm < 0 || (twin && xm != 1)) return GN_ERR_SHAPE;
   GroupTable<AggGroup> T{};
   T.n = n_groups;
   int wg = 0;
   for (int g = 0; g < n_groups; ++g) {
     const gn_agg_group_t& G = groups[g];
     if (G.A != nullptr) {
+      if (twin) return GN_ERR_SHAPE;
       GN_CHECK(need(G.A, true));
       if (G.N <= 0 || G.E != gn_pair_count(G.N) || G.rows % G.E != 0) return GN_ERR_SHAPE;
     } else if (G.eo != nullptr) {
@@ -1490,7 +971,7 @@ extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_str
       if (G.H == nullptr && G.E != (G.sym ? gn_pair_count(G.N) : G.N * G.N)) return GN_ERR_SHAPE;
       if (G.H != nullptr && G.sym) return GN_ERR_SHAPE;
     }
-    GN_CHECK(need(G.W, true));
+    GN_CHECK(need(xm ? (G.A != nullptr ? G.W2x : G.W12x) : (const void*)G.W, true));
     if (G.A == nullptr) GN_CHECK(need(G.b1, true));
     GN_CHECK(need(G.feat, true));
     GN_CHECK(need(G.edge_feat, false));
@@ -1529,8 +1010,19 @@ extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_str
     wg += ((T.g[g].a.rows + 31) / 32 * T.g[g].wpr + 3) / 4;
   }
   T.first_wg[n_groups] = wg;
-  hipLaunchKernelGGL(agg_mlp_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, T);
+  if (twin)
+    hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(wg), dim3(256), 0, stream, T);
+  else if (xm)
+    hipLaunchKernelGGL((agg_x_kernel<3, float>), dim3(wg), dim3(256), 0, stream, T);
+  else
+    hipLaunchKernelGGL(agg_mlp_kernel, dim3(wg), dim3(256), 0, stream, T);
   return gn_check_launch();
+}
+extern "C" int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream) {
+  return agg_launch(groups, n_groups, (hipStream_t)stream, false);
+}
+extern "C" int gn_agg_mlp_bf16(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream) {
+  return agg_launch(groups, n_groups, (hipStream_t)stream, true);
 }
 
 extern "C" int gn_node_linear_f32(const float* x, const float* W, const float* bias, float* y, int rows, int dout,
@@ -1543,10 +1035,38 @@ extern "C" int gn_node_linear_f32(const float* x, const float* W, const float* b
   return gn_check_launch();
 }
 
-extern "C" int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
-                           int N, float divisor, gn_stream_t stream) {
+template <int P, typename T>
+static int mlp2_x_launch(const GroupTable<gn_mlp2_group_t>& T_, int n_groups, int rows, int din, int dh, int dout, int ldy,
+                         int N, float divisor, hipStream_t s) {
+  const dim3 grid(row_grid(rows), n_groups), block(256);
+  const int OT = (dout + 31) / 32;
+#define GN_MLP2X(IT, HT, OTv) \
+  hipLaunchKernelGGL((mlp2_x_kernel<P, T, IT, HT, OTv>), grid, block, 0, s, T_, rows, dout, ldy, N, divisor)
+  if (din == 64 && dh == 128 && OT == 1) GN_MLP2X(2, 4, 1);
+  else if (din == 64 && dh == 128) GN_MLP2X(2, 4, 2);
+  else if (din == 128 && dh == 128 && OT == 1) GN_MLP2X(4, 4, 1);
+  else if (din == 128 && dh == 128) GN_MLP2X(4, 4, 2);
+  else if (din == 64 && dh == 256 && OT == 1) GN_MLP2X(2, 8, 1);
+  else if (din == 64 && dh == 256) GN_MLP2X(2, 8, 2);
+  else if (din == 128 && dh == 256 && OT == 1) GN_MLP2X(4, 8, 1);
+  else if (din == 128 && dh == 256) GN_MLP2X(4, 8, 2);
+  else return GN_ERR_SHAPE;
+#undef GN_MLP2X
+  return gn_check_launch();
+}
+
+static int mlp2_launch(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
+                       int N, float divisor, hipStream_t s, bool twin) {
   GN_CHECK(check_groups(groups, n_groups));
   if (rows <= 0 || dout <= 0 || ldy < dout) return GN_ERR_SHAPE;
+  int xm = x_mode(groups, n_groups, [](const gn_mlp2_group_t& G) { return G.Wx != nullptr; });
+  if (xm < 0) return GN_ERR_SHAPE;
+  if (twin && (xm != 1 || dout > 64)) return GN_ERR_SHAPE;
+  if (xm == 1 && dout > 64) {      // the bf16-core kernel keeps every output tile live: wide outputs use the plain stream
+    xm = 0;
+    for (int g = 0; g < n_groups; ++g)
+      if (groups[g].W == nullptr) return GN_ERR_NULL;
+  }
   GroupTable<gn_mlp2_group_t> T{};
   T.n = n_groups;
   for (int g = 0; g < n_groups; ++g) {
@@ -1560,13 +1080,15 @@ extern "C" int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows
       if (G.H == nullptr && G.E != (G.sym ? gn_pair_count(N) : N * N)) return GN_ERR_SHAPE;
       if (G.H != nullptr && G.sym) return GN_ERR_SHAPE;
     }
-    GN_CHECK(need(G.W, true));
+    GN_CHECK(need(xm ? G.Wx : (const void*)G.W, true));
     GN_CHECK(need(G.bias, true));
     GN_CHECK(need(G.y, false));
+    if (twin && (G.in_out != nullptr || G.hid_out != nullptr)) return GN_ERR_SHAPE;
     T.g[g] = G;
   }
+  if (twin) return mlp2_x_launch<1, __bf16>(T, n_groups, rows, din, dh, dout, ldy, N, divisor, s);
+  if (xm) return mlp2_x_launch<3, float>(T, n_groups, rows, din, dh, dout, ldy, N, divisor, s);
   const dim3 block(256);
-  hipStream_t s = (hipStream_t)stream;
   const int blocks32 = (rows + 31) / 32;
   bool fused = false;   // (also set when activations are to be kept: only the whole-chain kernel writes them)
   for (int g = 0; g < n_groups; ++g)
@@ -1596,4 +1118,12 @@ extern "C" int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows
   else
     return GN_ERR_SHAPE;
   return gn_check_launch();
+}
+extern "C" int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
+                           int N, float divisor, gn_stream_t stream) {
+  return mlp2_launch(groups, n_groups, rows, din, dh, dout, ldy, N, divisor, (hipStream_t)stream, false);
+}
+extern "C" int gn_mlp2_bf16(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
+                            int N, float divisor, gn_stream_t stream) {
+  return mlp2_launch(groups, n_groups, rows, din, dh, dout, ldy, N, divisor, (hipStream_t)stream, true);
 }

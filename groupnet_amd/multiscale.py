@@ -88,11 +88,13 @@ class MultiScaleHGNN(nn.Module):
         list of ``nmp_layers`` tensors; default draws as the modules do (reference order).
         ``advance`` = (counter, n): add n to the device Philox counter at the START of this forward
         (used by the captured graph so that every replay draws fresh noise)."""
-        ops._req(f, "f", (None, None, self.h_dim))
+        ops._req(f, "f", (None, None, self.h_dim), ops._ACT_DTYPES)
         B, N, D = f.shape
         S = len(self.hyper_scales)
         nmp = self.interaction.nmp_layers
         if _needs_grad(self, f):
+            if f.dtype != torch.float32:
+                raise NotImplementedError("the bf16 twins are forward-only: run them under torch.no_grad()")
             # training: ONE autograd node for the 1+S modules (grouped fused forward, grouped HIP backward);
             # the concat is an ordinary differentiable torch.cat
             if advance:
@@ -113,8 +115,8 @@ class MultiScaleHGNN(nn.Module):
                                              counter_add=advance[1] if advance else 0)
         elif S:
             # large N (N*(N+68)*4 B > LDS tile): banded affinity and banded top-k launches, plain copies
-            Hs = ops.topk_incidence(ops.affinity(f), self.hyper_scales)
-            new_H = torch.cat(Hs, dim=1)
+            Hs = ops.topk_incidence(ops.affinity(f if f.dtype == torch.float32 else f.float()), self.hyper_scales)
+            new_H = torch.cat(Hs, dim=1).to(f.dtype)
             final[..., :D].copy_(f)
             if advance:
                 ops.counter_add(advance[0], advance[1])

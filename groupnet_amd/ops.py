@@ -20,13 +20,18 @@ Tensor = torch.Tensor
 FEAT = 64
 
 
-def _req(t: Tensor, name: str, shape: Optional[Sequence[Optional[int]]] = None) -> Tensor:
+_ACT_DTYPES = (torch.float32, torch.bfloat16)   # storage types of activations: the *_f32 kernels and their *_bf16 twins
+
+
+def _req(t: Tensor, name: str, shape: Optional[Sequence[Optional[int]]] = None, dtype=torch.float32) -> Tensor:
+    """`dtype`: the required dtype, or a tuple of admissible ones (activations: fp32 or the bf16 twins)."""
     if not isinstance(t, torch.Tensor):
         raise ValueError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
     if not t.is_cuda:
         raise ValueError(f"{name}: must live on the GPU (got device {t.device}); groupnet_amd has no CPU path")
-    if t.dtype != torch.float32:
-        raise ValueError(f"{name}: must be float32 (got {t.dtype})")
+    if (t.dtype not in dtype) if isinstance(dtype, tuple) else (t.dtype != dtype):
+        want = " or ".join(str(d) for d in dtype) if isinstance(dtype, tuple) else str(dtype)
+        raise ValueError(f"{name}: must be {want} (got {t.dtype})")
     if not t.is_contiguous():
         raise ValueError(f"{name}: must be contiguous")
     if shape is not None:
@@ -53,7 +58,57 @@ def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
 launch_probe = None
 
 
-BF16X6 = os.environ.get("GN_BF16X6", "1") != "0"   # fp32-accurate products on the bf16 cores (agg, edge kernels)
+BF16X6 = os.environ.get("GN_BF16X6", "1") != "0"   # fp32 entry points: fp32-accurate products on the bf16 cores
+
+
+def _twin(dtype: torch.dtype) -> bool:
+    return dtype == torch.bfloat16
+
+
+def _fn(stem: str, dtype: torch.dtype):
+    """The C entry point of a stage for a storage type: `<stem>_f32` or its `<stem>_bf16` twin."""
+    return getattr(load(), stem + ("_bf16" if _twin(dtype) else "_f32"))
+
+
+class XImages:
+    """bf16-core weight images of one packed-weight set (`gn_split_bf16_f32`), built on demand per number of
+    parts (3: the fp32-accurate path of the fp32 entry points, 1: the bf16 twins) from hidden-tile-major fp32
+    tile streams of a `PackPlan` arena, and rebuilt whenever the owner bumps `version` after a refresh."""
+
+    def __init__(self):
+        self.src = {}
+        self.img = {}
+        self.version = 0
+
+    def add(self, name: str, tiles: Tensor) -> None:
+        self.src[name] = tiles
+
+    def bump(self) -> None:
+        self.version += 1
+
+    def get(self, name: str, parts: int) -> Tensor:
+        hit = self.img.get((name, parts))
+        src = self.src[name]
+        if hit is None:
+            hit = self.img[(name, parts)] = [torch.empty(src.numel() // 1024 * 2 * parts * 64 * 8, dtype=torch.int16,
+                                                         device=src.device), -1]
+        if hit[1] != self.version:
+            split_bf16(src, hit[0], parts)
+            hit[1] = self.version
+        return hit[0]
+
+
+def _ximg(pk: dict, name: str, dtype: torch.dtype) -> int:
+    """Device address of image `name` for a launch on `dtype` activations, or 0 (fp32 entry point with the
+    bf16-core path switched off: the launch then uses the plain packed stream on the fp32 matrix cores)."""
+    xi = pk.get("xi")
+    if _twin(dtype):
+        if xi is None or name not in xi.src:
+            raise ValueError(f"no bf16 image '{name}' for this weight set")
+        return xi.get(name, 1).data_ptr()
+    if not BF16X6 or xi is None or name not in xi.src:
+        return 0
+    return xi.get(name, 3).data_ptr()
 
 
 class _Probed:
@@ -83,14 +138,14 @@ def affinity(f: Tensor) -> Tensor:
     return corr
 
 
-def _alloc_incidence(B: int, N: int, scales: Sequence[int], like: Tensor) -> List[Tensor]:
+def _alloc_incidence(B: int, N: int, scales: Sequence[int], device) -> List[Tensor]:
     out = []
     for s in scales:
         s = int(s)
         if s > N:
             raise RuntimeError("selected index k out of range")  # what torch.topk raises (MS_HGNN_batch.py:382)
         E = 1 if s == N else N
-        out.append(torch.empty((B, E, N), dtype=like.dtype, device=like.device))
+        out.append(torch.empty((B, E, N), dtype=torch.float32, device=device))
     return out
 
 
@@ -109,7 +164,7 @@ def topk_incidence(corr: Tensor, scales: Sequence[int]) -> List[Tensor]:
         raise ValueError(f"corr: expected (B,N,N), got {tuple(corr.shape)}")
     if not 1 <= len(scales) <= 8:
         raise ValueError("between 1 and 8 scales per call")
-    Hs = _alloc_incidence(B, N, scales, corr)
+    Hs = _alloc_incidence(B, N, scales, corr.device)
     Hl, kl, n = _scale_args(Hs, scales)
     with torch.cuda.device(corr.device):
         check(load().gn_topk_incidence_f32(_ptr(corr), Hl, kl, n, B, N, stream_handle()), "gn_topk_incidence_f32")
@@ -162,17 +217,19 @@ def affinity_topk(f: Optional[Tensor], scales: Sequence[int], want_corr: bool = 
         _same_device(x_raw, M, c)
         f_contig = torch.empty((B, N, D), dtype=x_raw.dtype, device=x_raw.device)
         f = f_contig          # shapes / device for the allocations below; the kernel ignores its contents
-    _req(f, "f", (None, None, None))
+    _req(f, "f", (None, None, None), _ACT_DTYPES)
+    if _twin(f.dtype) and embed is not None:
+        raise ValueError("the embedding front-end is fp32 only")
     B, N, D = f.shape
-    corr = torch.empty((B, N, N), dtype=f.dtype, device=f.device) if want_corr else None
-    Hs = _alloc_incidence(B, N, scales, f)
+    corr = torch.empty((B, N, N), dtype=torch.float32, device=f.device) if want_corr else None
+    Hs = _alloc_incidence(B, N, scales, f.device)
     Hl, kl, n = _scale_args(Hs, scales)
     ex = _lib.BlockExtras()
     H_cat = None
     if f_out is not None:
-        if not (f_out.is_cuda and f_out.dtype == torch.float32 and tuple(f_out.shape) == (B, N, D)
+        if not (f_out.is_cuda and f_out.dtype == f.dtype and tuple(f_out.shape) == (B, N, D)
                 and f_out.stride(2) == 1 and f_out.stride(0) == N * f_out.stride(1)):
-            raise ValueError("f_out: a (B,N,D) last-dim slice of a contiguous float32 GPU tensor")
+            raise ValueError("f_out: a (B,N,D) last-dim slice of a contiguous GPU tensor of f's dtype")
         ex.f_out, ex.f_out_ld = f_out.data_ptr(), f_out.stride(1)
     if want_H_cat:
         H_cat = torch.empty((B, sum(h.shape[1] for h in Hs), N), dtype=f.dtype, device=f.device)
@@ -185,8 +242,8 @@ def affinity_topk(f: Optional[Tensor], scales: Sequence[int], want_corr: bool = 
         ex.x_raw, ex.x_dim, ex.M, ex.c, ex.f_contig = (embed[0].data_ptr(), embed[0].shape[2], embed[1].data_ptr(),
                                                       embed[2].data_ptr(), f_contig.data_ptr())
     with torch.cuda.device(f.device):
-        check(load().gn_affinity_topk_f32(_ptr(f), _ptr(corr), Hl, kl, n, B, N, D, ctypes.byref(ex), stream_handle()),
-              "gn_affinity_topk_f32")
+        check(_fn("gn_affinity_topk", f.dtype)(_ptr(f), _ptr(corr), Hl, kl, n, B, N, D, ctypes.byref(ex),
+                                               stream_handle()), "gn_affinity_topk")
     if embed is not None:
         return corr, Hs, H_cat, f_contig
     return corr, Hs, H_cat
@@ -335,30 +392,58 @@ def _groups(n: int) -> None:
         raise ValueError(f"1..{_lib.MAX_GROUPS} groups per launch, got {n}")
 
 
-def node_mlp_grouped(items: Sequence[Tuple[Tensor, dict]], keep: Optional[List[dict]] = None
-                     ) -> List[Tuple[Tensor, Tensor]]:
-    """One launch for several modules: items = [(x (B,N,64), pk{"W","bias"})] with equal shapes;
-    returns [(x', pq)].  ``keep`` (training) receives per group {"hid": relu(W0 x + b0) (rows, 256)}."""
+def node_stage_grouped(items: Sequence[Tuple[Tensor, dict]], keep: Optional[List[dict]] = None,
+                       a_specs: Optional[Sequence[Optional[Tuple[dict, int]]]] = None
+                       ) -> Tuple[List[Tuple[Tensor, Tensor]], List[Optional[Tensor]]]:
+    """One launch for the node rows of several modules: items = [(x (B,N,64), pk{"W","bias","xi"})] with equal
+    shapes -> [(x', pq)].  ``keep`` (training) receives per group {"hid": relu(W0 x + b0) (rows, 256)}.
+    ``a_specs[g]`` = (agg_pk, K) asks for the per-node first layer of the typed aggregation MLP of the pairwise
+    graph, A = W1cat x + b1/2 (B,N,K*128), from the SAME launch (bf16-core path of the fp32 entry point; with
+    that path switched off it is a `node_linear` launch of its own); returned as the second list."""
     _groups(len(items))
-    x0 = _req(items[0][0], "x", (None, None, FEAT))
+    x0 = _req(items[0][0], "x", (None, None, FEAT), _ACT_DTYPES)
+    dt = x0.dtype
     rows = x0.shape[0] * x0.shape[1]
     arr = (_lib.NodeGroup * len(items))()
-    outs = []
+    outs, As, late = [], [], []
     for g, (x, pk) in enumerate(items):
-        _req(x, "x", tuple(x0.shape))
+        _req(x, "x", tuple(x0.shape), dt)
         _same_device(x0, x)
         xp, pq = torch.empty_like(x), torch.empty_like(x)
         hid_ptr = 0
         if keep is not None:
+            if _twin(dt):
+                raise ValueError("the bf16 twins are forward-only")
             keep.append(dict(hid=torch.empty((rows, 256), dtype=x.dtype, device=x.device)))
             hid_ptr = keep[-1]["hid"].data_ptr()
+        wx = _ximg(pk, "chain", dt)
+        a_fields = (0, 0, 0, 0)
+        A = None
+        spec = a_specs[g] if a_specs is not None else None
+        if spec is not None:
+            if _twin(dt):
+                raise ValueError("the per-node first layer (pair form) belongs to the fp32 entry points")
+            apk, K = spec
+            if wx:
+                A = torch.empty(tuple(x.shape[:-1]) + (K * 128,), dtype=x.dtype, device=x.device)
+                a_fields = (_ximg(apk, "W1cat", dt), apk["b1half"].data_ptr(), A.data_ptr(), K)
+            else:
+                late.append((g, x, apk, K))
+        As.append(A)
         arr[g] = _lib.NodeGroup(x.data_ptr(), pk["W"].data_ptr(), pk["bias"].data_ptr(), xp.data_ptr(), pq.data_ptr(),
-                                hid_ptr)
+                                hid_ptr, wx, *a_fields)
         outs.append((xp, pq))
-    flops = len(items) * rows * 2 * (64 * 256 + 256 * 64 + 64 * 64)
-    with torch.cuda.device(x0.device), _Probed("node_mlp_kernel", flops):
-        check(load().gn_node_mlp_f32(arr, len(items), rows, stream_handle()), "gn_node_mlp_f32")
-    return outs
+    flops = sum(rows * 2 * (64 * 256 + 256 * 64 + 64 * 64 + (64 * 128 * int(a.KA) if a.A else 0)) for a in arr)
+    with torch.cuda.device(x0.device), _Probed("node_stage_kernel", flops):
+        check(_fn("gn_node_mlp", dt)(arr, len(items), rows, stream_handle()), "gn_node_mlp")
+    for g, x, apk, K in late:
+        As[g] = node_linear(x, apk["W1cat"], apk["b1half"], K * 128)
+    return outs, As
+
+
+def node_mlp_grouped(items: Sequence[Tuple[Tensor, dict]], keep: Optional[List[dict]] = None
+                     ) -> List[Tuple[Tensor, Tensor]]:
+    return node_stage_grouped(items, keep)[0]
 
 
 def node_mlp(x: Tensor, pk: dict) -> Tuple[Tensor, Tensor]:
@@ -377,15 +462,16 @@ def node2edge_grouped(items: Sequence[tuple]) -> List[Tensor]:
     H=None selects the implicit pairwise graph: E = N*N ordered edges, or with sym=True the
     N(N+1)/2 unordered pairs (edges (i,j) and (j,i) carry the same feature)."""
     _groups(len(items))
-    xp0 = _req(items[0][0], "xp", (None, None, FEAT))
+    xp0 = _req(items[0][0], "xp", (None, None, FEAT), _ACT_DTYPES)
+    dt = xp0.dtype
     B, N, _ = xp0.shape
     arr = (_lib.N2EGroup * len(items))()
     outs = []
     for g, item in enumerate(items):
         xp, pq, H, w2, b2 = item[:5]
         sym = bool(item[5]) if len(item) > 5 else False
-        _req(xp, "xp", (B, N, FEAT))
-        _req(pq, "pq", (B, N, FEAT))
+        _req(xp, "xp", (B, N, FEAT), dt)
+        _req(pq, "pq", (B, N, FEAT), dt)
         if H is None:
             E = pair_count(N) if sym else N * N
         else:
@@ -401,7 +487,7 @@ def node2edge_grouped(items: Sequence[tuple]) -> List[Tensor]:
                                edges.data_ptr(), b2.data_ptr(), E, int(sym))
         outs.append(edges)
     with torch.cuda.device(xp0.device):
-        check(load().gn_node2edge_f32(arr, len(items), B, N, stream_handle()), "gn_node2edge_f32")
+        check(_fn("gn_node2edge", dt)(arr, len(items), B, N, stream_handle()), "gn_node2edge")
     return outs
 
 
@@ -432,7 +518,8 @@ def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5, keep: Opti
     ``keep`` (training) receives per group the activations the kernel otherwise holds in registers:
     {"z1" (rows,128), "z" (rows,64), "dh1" (rows,256), "lgf" (rows,32)}."""
     _groups(len(items))
-    e0 = items[0][0]
+    e0 = _req(items[0][0], "edges", (None, None, FEAT), _ACT_DTYPES)
+    dt = e0.dtype
     arr = (_lib.EdgeGroup * len(items))()
     outs = []
     seed, ctr = None, None
@@ -440,7 +527,7 @@ def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5, keep: Opti
         edges, U, pk, K = item[:4]
         sym_N = int(item[4]) if len(item) > 4 else 0
         want_dist = bool(item[5]) if len(item) > 5 else True
-        _req(edges, "edges", (None, None, FEAT))
+        _req(edges, "edges", (None, None, FEAT), dt)
         _same_device(e0, edges)
         B, E, _ = edges.shape
         if sym_N and E != pair_count(sym_N):
@@ -456,22 +543,23 @@ def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5, keep: Opti
             _req(U, "noise_u", (B, Eo, K))
             _same_device(edges, U)
             u_ptr, off = U.data_ptr(), 0
-        edge_feat = torch.empty((B, E, K), dtype=edges.dtype, device=edges.device)
-        dist = torch.empty((B, Eo, K), dtype=edges.dtype, device=edges.device) if (want_dist or not sym_N) else None
+        edge_feat = torch.empty((B, E, K), dtype=torch.float32, device=edges.device)    # always fp32: a VALU scale
+        dist = torch.empty((B, Eo, K), dtype=dt, device=edges.device) if (want_dist or not sym_N) else None
         kp = (0, 0, 0, 0)
         if keep is not None:
+            if _twin(dt):
+                raise ValueError("the bf16 twins are forward-only")
             mk = lambda w: torch.empty((B * E, w), dtype=edges.dtype, device=edges.device)
             keep.append(dict(z1=mk(128), z=mk(64), dh1=mk(256), lgf=mk(32)))
             kp = tuple(keep[-1][n].data_ptr() for n in ("z1", "z", "dh1", "lgf"))
-        wx3 = pk.get("Wx3") if BF16X6 else None
         arr[g] = _lib.EdgeGroup(edges.data_ptr(), u_ptr, pk["W"].data_ptr(), pk["bias"].data_ptr(),
                                 edge_feat.data_ptr(), 0 if dist is None else dist.data_ptr(), off, B * E, K, sym_N, *kp,
-                                0 if wx3 is None else wx3.data_ptr())
+                                _ximg(pk, "edge", dt))
         outs.append((edge_feat, dist))
     flops = sum(int(a.rows) for a in arr) * 2 * (64 * 128 + 128 * 64 + 64 * 256 + 256 * 32)
     with torch.cuda.device(e0.device), _Probed("edge_mlp_gumbel_kernel", flops):
-        check(load().gn_edge_mlp_gumbel_f32(arr, len(items), float(tau), seed or 0, _ptr(ctr), stream_handle()),
-              "gn_edge_mlp_gumbel_f32")
+        check(_fn("gn_edge_mlp_gumbel", dt)(arr, len(items), float(tau), seed or 0, _ptr(ctr), stream_handle()),
+              "gn_edge_mlp_gumbel")
     return outs
 
 
@@ -493,21 +581,22 @@ def _edge_count(H: Optional[Tensor], B: int, N: int, sym: bool = False) -> int:
 def agg_gather_grouped(items: Sequence[tuple]) -> List[Tensor]:
     """items = [(ori (B,N,64), H (B,E,N) or None[, sym])] -> [eo (B,E,64)]."""
     _groups(len(items))
-    o0 = _req(items[0][0], "ori", (None, None, FEAT))
+    o0 = _req(items[0][0], "ori", (None, None, FEAT), _ACT_DTYPES)
+    dt = o0.dtype
     B, N, _ = o0.shape
     arr = (_lib.GatherGroup * len(items))()
     outs = []
     for g, item in enumerate(items):
         ori, H = item[:2]
         sym = bool(item[2]) if len(item) > 2 else False
-        _req(ori, "ori", (B, N, FEAT))
+        _req(ori, "ori", (B, N, FEAT), dt)
         E = _edge_count(H, B, N, sym)
         _same_device(o0, ori, H)
         eo = torch.empty((B, E, FEAT), dtype=ori.dtype, device=ori.device)
         arr[g] = _lib.GatherGroup(ori.data_ptr(), 0 if H is None else H.data_ptr(), eo.data_ptr(), E, int(sym))
         outs.append(eo)
     with torch.cuda.device(o0.device):
-        check(load().gn_agg_gather_f32(arr, len(items), B, N, stream_handle()), "gn_agg_gather_f32")
+        check(_fn("gn_agg_gather", dt)(arr, len(items), B, N, stream_handle()), "gn_agg_gather")
     return outs
 
 
@@ -533,26 +622,27 @@ class PairSpec:
         self.A = A
 
 
-def split_bf16x3(packed: Tensor, out: Optional[Tensor] = None) -> Tensor:
-    """Three-bf16-part image (16-bit words, as int16) of packed fp32 32x32 weight tiles: `gn_split_bf16x3_f32`."""
+def split_bf16(packed: Tensor, out: Optional[Tensor] = None, parts: int = 3) -> Tensor:
+    """bf16-core image (16-bit words, as int16) of packed fp32 32x32 weight tiles: `gn_split_bf16_f32`
+    (parts = 3: x = p1 + p2 + p3, the fp32-accurate path; parts = 1: x rounded to bf16, the twins)."""
     _req(packed, "packed")
     n_tiles = packed.numel() // 1024
     if out is None:
-        out = torch.empty(n_tiles * 2 * 3 * 64 * 8, dtype=torch.int16, device=packed.device)
+        out = torch.empty(n_tiles * 2 * parts * 64 * 8, dtype=torch.int16, device=packed.device)
     with torch.cuda.device(packed.device):
-        check(load().gn_split_bf16x3_f32(_ptr(packed), ctypes.c_void_p(out.data_ptr()), n_tiles, stream_handle()),
-              "gn_split_bf16x3_f32")
+        check(load().gn_split_bf16_f32(_ptr(packed), ctypes.c_void_p(out.data_ptr()), n_tiles, int(parts),
+                                       stream_handle()), "gn_split_bf16_f32")
     return out
 
 
 def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[Tensor]:
-    """items = [(eo (B,E,64) | GatherSpec | PairSpec, edge_feat (B,E,K), pk{"W","b1","b2"[,"W2t"]}, K)]
-    -> [feat (B,E,64)]."""
+    """items = [(eo (B,E,64) | GatherSpec | PairSpec, edge_feat (B,E,K) fp32, pk{"W","b1","b2","xi"[,"W2t"]}, K)]
+    -> [feat (B,E,64)] in the storage type of the inputs (bf16 twin: eo / GatherSpec only)."""
     _groups(len(items))
     arr = (_lib.AggGroup * len(items))()
     outs = []
     flops = 0
-    dev0 = None
+    dev0 = dt = None
     for g, (eo, edge_feat, pk, K) in enumerate(items):
         wkey = "W"
         if isinstance(eo, PairSpec):
@@ -562,28 +652,25 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
             E = pair_count(N)
             _same_device(A, edge_feat)
             like, eo_ptr, wkey = A, 0, "W2t"
-            w3 = pk.get("W2x3") if BF16X6 else None
-            extra = (0, 0, E, N, 1, A.data_ptr(), 0 if w3 is None else w3.data_ptr(), 0)
+            extra = (0, 0, E, N, 1, A.data_ptr(), _ximg(pk, "W2t", A.dtype), 0)
         elif isinstance(eo, GatherSpec):
             ori, H = eo.ori, eo.H
-            _req(ori, "ori", (None, None, FEAT))
+            _req(ori, "ori", (None, None, FEAT), _ACT_DTYPES)
             B, N, _ = ori.shape
             E = _edge_count(H, B, N, eo.sym)
             _same_device(ori, H, edge_feat)
             like, eo_ptr = ori, 0
-            w12 = pk.get("W12x3") if BF16X6 else None
             extra = (ori.data_ptr(), 0 if H is None else H.data_ptr(), E, N, int(eo.sym), 0, 0,
-                     0 if w12 is None else w12.data_ptr())
+                     _ximg(pk, "W12", ori.dtype))
         else:
-            _req(eo, "eo", (None, None, FEAT))
+            _req(eo, "eo", (None, None, FEAT), _ACT_DTYPES)
             B, E, _ = eo.shape
             _same_device(eo, edge_feat)
             like, eo_ptr = eo, eo.data_ptr()
-            w12 = pk.get("W12x3") if BF16X6 else None
-            extra = (0, 0, 0, 0, 0, 0, 0, 0 if w12 is None else w12.data_ptr())
-        dev0 = dev0 or like.device
-        if like.device != dev0:
-            raise ValueError("grouped launch: every group must be on the same device")
+            extra = (0, 0, 0, 0, 0, 0, 0, _ximg(pk, "W12", eo.dtype))
+        dev0, dt = dev0 or like.device, dt or like.dtype
+        if like.device != dev0 or like.dtype != dt:
+            raise ValueError("grouped launch: every group must be on the same device and of the same storage type")
         _req(edge_feat, "edge_feat", (B, E, K))
         feat = torch.empty((B, E, FEAT), dtype=like.dtype, device=like.device)
         arr[g] = _lib.AggGroup(eo_ptr, edge_feat.data_ptr(), pk[wkey].data_ptr(), pk["b1"].data_ptr(),
@@ -592,7 +679,7 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
         # executed FLOPs: both layers, or the second layer only in the pair form
         flops += B * E * K * ((2 * 128 * 64 + 2 * 64) + (0 if wkey == "W2t" else 2 * 64 * 128))
     with torch.cuda.device(dev0), _Probed("agg_mlp_kernel", flops):
-        check(load().gn_agg_mlp_f32(arr, len(items), stream_handle()), "gn_agg_mlp_f32")
+        check(_fn("gn_agg_mlp", dt)(arr, len(items), stream_handle()), "gn_agg_mlp")
     return outs
 
 
@@ -617,24 +704,25 @@ def agg_scatter_grouped(items: Sequence[tuple], divisor: Optional[float] = None)
     """items = [(feat (B,E,64), H or None, ori (B,N,64)[, sym])] -> [cat(H^T feat, ori) / divisor
     (B,N,128)]; divisor defaults to N (edge2node, model/MS_HGNN_batch.py:120,355)."""
     _groups(len(items))
-    o0 = _req(items[0][2], "ori", (None, None, FEAT))
+    o0 = _req(items[0][2], "ori", (None, None, FEAT), _ACT_DTYPES)
+    dt = o0.dtype
     B, N, _ = o0.shape
     arr = (_lib.ScatterGroup * len(items))()
     outs = []
     for g, item in enumerate(items):
         feat, H, ori = item[:3]
         sym = bool(item[3]) if len(item) > 3 else False
-        _req(ori, "ori", (B, N, FEAT))
+        _req(ori, "ori", (B, N, FEAT), dt)
         E = _edge_count(H, B, N, sym)
-        _req(feat, "feat", (B, E, FEAT))
+        _req(feat, "feat", (B, E, FEAT), dt)
         _same_device(o0, feat, ori, H)
         out = torch.empty((B, N, 2 * FEAT), dtype=ori.dtype, device=ori.device)
         arr[g] = _lib.ScatterGroup(feat.data_ptr(), 0 if H is None else H.data_ptr(), ori.data_ptr(), out.data_ptr(), E,
                                    int(sym))
         outs.append(out)
     with torch.cuda.device(o0.device):
-        check(load().gn_agg_scatter_f32(arr, len(items), B, N, float(N if divisor is None else divisor),
-                                        stream_handle()), "gn_agg_scatter_f32")
+        check(_fn("gn_agg_scatter", dt)(arr, len(items), B, N, float(N if divisor is None else divisor),
+                                        stream_handle()), "gn_agg_scatter")
     return outs
 
 
@@ -647,8 +735,8 @@ def agg_scatter(feat: Tensor, H: Optional[Tensor], ori: Tensor, divisor: Optiona
 def _mlp2_out(lead: Tuple[int, ...], dout: int, out: Optional[Tensor], like: Tensor) -> Tuple[Tensor, int]:
     if out is None:
         return torch.empty(tuple(lead) + (dout,), dtype=like.dtype, device=like.device), dout
-    if not (out.is_cuda and out.dtype == torch.float32 and out.device == like.device):
-        raise ValueError("out: must be a float32 tensor on the input's device")
+    if not (out.is_cuda and out.dtype == like.dtype and out.device == like.device):
+        raise ValueError("out: must be a tensor of the input's dtype on the input's device")
     if tuple(out.shape) != tuple(lead) + (dout,) or out.stride(-1) != 1:
         raise ValueError(f"out: expected shape {tuple(lead) + (dout,)} with unit inner stride")
     ldy = out.stride(-2) if out.dim() >= 2 else dout
@@ -679,17 +767,17 @@ def mlp2_grouped(items: Sequence[Tuple[object, dict, Optional[Tensor]]], keep: O
     pk0 = items[0][1]
     din, dh, dout = pk0["din"], pk0["dh"], pk0["dout"]
     arr = (_lib.Mlp2Group * len(items))()
-    outs, ld0, shape0, dev0, N, divisor = [], None, None, None, 0, 1.0
+    outs, ld0, shape0, dev0, N, divisor, dt = [], None, None, None, 0, 1.0, None
     for g, (x, pk, out) in enumerate(items):
         if (pk["din"], pk["dh"], pk["dout"]) != (din, dh, dout):
             raise ValueError("grouped mlp2: every group must have the same layer widths")
         if isinstance(x, ScatterSpec):
             if din != 2 * FEAT:
                 raise ValueError("ScatterSpec feeds a 128-wide MLP")
-            _req(x.ori, "ori", (None, None, FEAT))
+            _req(x.ori, "ori", (None, None, FEAT), _ACT_DTYPES)
             B, Nn, _ = x.ori.shape
             E = _edge_count(x.H, B, Nn, x.sym)
-            _req(x.feat, "feat", (B, E, FEAT))
+            _req(x.feat, "feat", (B, E, FEAT), x.ori.dtype)
             _same_device(x.ori, x.feat, x.H)
             d = float(Nn if x.divisor is None else x.divisor)
             if N and (N, divisor) != (Nn, d):
@@ -699,15 +787,15 @@ def mlp2_grouped(items: Sequence[Tuple[object, dict, Optional[Tensor]]], keep: O
             fields = (0, pk["W"].data_ptr(), pk["bias"].data_ptr(), None, x.feat.data_ptr(),
                       0 if x.H is None else x.H.data_ptr(), x.ori.data_ptr(), E, int(x.sym))
         else:
-            _req(x, "x")
+            _req(x, "x", None, _ACT_DTYPES)
             if x.shape[-1] != din:
                 raise ValueError(f"x: last dim {x.shape[-1]} != {din}")
             lead, like = tuple(x.shape[:-1]), x
             fields = (x.data_ptr(), pk["W"].data_ptr(), pk["bias"].data_ptr(), None, 0, 0, 0, 0, 0)
         if shape0 is None:
-            shape0, dev0 = lead, like.device
-        elif lead != shape0 or like.device != dev0:
-            raise ValueError("grouped mlp2: every group must have the same leading shape and device")
+            shape0, dev0, dt = lead, like.device, like.dtype
+        elif lead != shape0 or like.device != dev0 or like.dtype != dt:
+            raise ValueError("grouped mlp2: every group must have the same leading shape, device and storage type")
         y, ldy = _mlp2_out(lead, dout, out, like)
         if ld0 is None:
             ld0 = ldy
@@ -715,6 +803,8 @@ def mlp2_grouped(items: Sequence[Tuple[object, dict, Optional[Tensor]]], keep: O
             raise ValueError("grouped mlp2: every group must have the same output row stride")
         kp = (0, 0)
         if keep is not None:
+            if _twin(dt):
+                raise ValueError("the bf16 twins are forward-only")
             nrow = 1
             for d_ in lead:
                 nrow *= int(d_)
@@ -722,15 +812,16 @@ def mlp2_grouped(items: Sequence[Tuple[object, dict, Optional[Tensor]]], keep: O
                       hid=torch.empty((nrow, dh), dtype=like.dtype, device=like.device))
             keep.append(kd)
             kp = (kd["x"].data_ptr(), kd["hid"].data_ptr())
-        arr[g] = _lib.Mlp2Group(fields[0], fields[1], fields[2], y.data_ptr(), *fields[4:], *kp)
+        arr[g] = _lib.Mlp2Group(fields[0], fields[1], fields[2], y.data_ptr(), *fields[4:], *kp,
+                                _ximg(pk, "mlp2", dt) if dout <= 64 else 0)
         outs.append(y)
     rows = 1
     for d_ in shape0:
         rows *= int(d_)
     flops = len(items) * rows * 2 * (din * dh + dh * (((dout + 31) // 32) * 32))
     with torch.cuda.device(dev0), _Probed("mlp2_kernel", flops):
-        check(load().gn_mlp2_f32(arr, len(items), rows, din, dh, dout, ld0, N, divisor, stream_handle()),
-              "gn_mlp2_f32")
+        check(_fn("gn_mlp2", dt)(arr, len(items), rows, din, dh, dout, ld0, N, divisor, stream_handle()),
+              "gn_mlp2")
     return outs
 
 

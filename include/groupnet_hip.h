@@ -17,6 +17,18 @@
  *   - "packed" weights are produced by gn_pack_linear_f32 from an nn.Linear weight
  *     (out x in, row-major); the layout is private to the library.  A kernel that applies several
  *     layers takes ONE buffer holding their packed images back to back, in the order stated.
+ *   - bf16 twins (BASELINE config 4: bf16 storage, fp32 accumulate): every stage of the forward
+ *     has a *_bf16 entry point taking the SAME descriptor structs.  In a twin the fields marked [T] point to
+ *     bf16 tensors (2 bytes per element, 8-byte aligned rows) instead of fp32; incidence H, uniforms U,
+ *     edge_feat, biases and the small attention vectors stay fp32; weights are given as the one-part bf16
+ *     image (`Wx` fields, gn_split_bf16_f32 with parts = 1).  Products run on v_mfma_f32_32x32x16_bf16 with
+ *     fp32 accumulation; a layer's fp32 result is rounded to bf16 (nearest even) when it becomes the next
+ *     layer's operand or is stored.  The twins are forward-only (the optional training outputs must be NULL).
+ *   - `Wx` images: the fp32-accurate bf16-core path of the *_f32 entry points.  A group that carries `Wx`
+ *     (gn_split_bf16_f32 with parts = 3: every weight as three bf16 parts) is evaluated with six bf16
+ *     part-products per product on the bf16 matrix cores — as accurate as fp32 accumulation, faster than the
+ *     fp32 matrix cores; without it the launch falls back to v_mfma_f32_32x32x2_f32 on the plain packed stream.
+ *     Either all groups of a launch carry it or none.
  */
 #ifndef GROUPNET_HIP_H
 #define GROUPNET_HIP_H
@@ -101,6 +113,12 @@ typedef struct {
 int gn_affinity_topk_f32(const float* f, float* corr, float* const* H_list, const int* k_list,
                          int n_scales, int B, int N, int D, const gn_block_extras_t* extras,
                          gn_stream_t stream);
+/* twin: f, extras->f_out and extras->H_cat are bf16 (H values 0/1 are exact in bf16); the normalisation, the
+ * affinity and the ranking run in fp32 on the bf16 inputs, corr (may be NULL) and every H_s stay fp32; the
+ * embedding front-end (extras->x_raw) is not part of the twin. */
+int gn_affinity_topk_bf16(const void* f, float* corr, float* const* H_list, const int* k_list,
+                          int n_scales, int B, int N, int D, const gn_block_extras_t* extras,
+                          gn_stream_t stream);
 
 /* ---- weight packing -------------------------------------------------------------------
  * Number of floats of the packed image of an (out x in) nn.Linear weight. */
@@ -145,14 +163,25 @@ int gn_pack_segments_f32(const gn_pack_seg_t* segs, int n_segs, int max_elems, g
  *        consumed in this order); bias = [b0 (256) | b1 (64) | bpq (64)].
  * x (rows,64) -> xp (rows,64), pq (rows,64) per group. */
 typedef struct {
-  const float* x;
+  const float* x;   /* [T] */
   const float* W;
   const float* bias;
-  float* xp;
-  float* pq;
+  float* xp;        /* [T] */
+  float* pq;        /* [T] */
   float* hid_out;   /* optional (training): the hidden activations relu(W0 x + b0) (rows, 256) */
+  const void* Wx;   /* optional bf16-core image of the chain, hidden-tile-major (72 sub-steps): per hidden tile t
+                       of W0 the tiles [W0(t,in0), W0(t,in1), W1(0,t), W1(1,t)], then [Wpq(0,in0), Wpq(0,in1),
+                       Wpq(1,in0), Wpq(1,in1)].  With it W may be NULL. */
+  /* optional, with Wx only: the per-node first layer of the typed aggregation MLP of the pairwise graph in the
+   * SAME launch (it reads the same node rows; see gn_node_linear_f32): A = WA x + bA, A (rows, KA*128) [T],
+   * WAx = bf16-core image of the packed (KA*128 x 64) matrix, bA (KA*128) fp32.  A == NULL: not computed. */
+  const void* WAx;
+  const float* bA;
+  float* A;         /* [T] */
+  int KA;
 } gn_node_group_t;
 int gn_node_mlp_f32(const gn_node_group_t* groups, int n_groups, int rows, gn_stream_t stream);
+int gn_node_mlp_bf16(const gn_node_group_t* groups, int n_groups, int rows, gn_stream_t stream);
 
 /* ---- A3 (second half): attention-weighted node -> edge pooling ---------------------------
  * Replaces the rest of node2edge, MS_HGNN_batch.py:127-141 / 359-370:
@@ -165,17 +194,18 @@ int gn_node_mlp_f32(const gn_node_group_t* groups, int n_groups, int rows, gn_st
  * the same pooled feature, so only the N(N+1)/2 unordered pairs are produced: E = N(N+1)/2, row
  * p(i,j) = i*N - i(i-1)/2 + (j-i) for i <= j.  Every pairwise stage below has the matching form. */
 typedef struct {
-  const float* xp;
-  const float* pq;
+  const float* xp;   /* [T] */
+  const float* pq;   /* [T] */
   const float* H;
   const float* w2;
-  float* edges;
+  float* edges;      /* [T] */
   const float* b2;   /* device pointer to the scalar bias of attention layer 1 (the parameter itself: no
                         host read-back, so a training step stays capturable in a hipGraph) */
   int E;
   int sym;
 } gn_n2e_group_t;
 int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, gn_stream_t stream);
+int gn_node2edge_bf16(const gn_n2e_group_t* groups, int n_groups, int B, int N, gn_stream_t stream);
 
 /* ---- A4: per-edge MLPs + Gumbel-softmax edge typing ----------------------------------------
  * Replaces MLP_dict_softmax.forward + gumbel_softmax, MS_HGNN_batch.py:41-53,446-520:
@@ -199,12 +229,12 @@ int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, g
  * fac*(dist_ij + dist_ji) (2*fac*dist_ii on the diagonal) — exactly the weight the pair carries in the
  * edge->node sum, where both ordered edges meet the same typed MLP output. */
 typedef struct {
-  const float* edges;
+  const float* edges;   /* [T] */
   const float* U;
   const float* W;
   const float* bias;
   float* edge_feat;
-  float* dist;
+  float* dist;          /* [T] */
   unsigned long long philox_offset;
   int rows;
   int K;
@@ -216,26 +246,29 @@ typedef struct {
   float* keep_z;
   float* keep_dh1;
   float* keep_lgf;
-  const void* Wx3;   /* optional: the four layers as three bf16 parts (gn_split_bf16x3_f32) of the hidden-tile-major
-                        fp32 stream — per hidden tile t of init_MLP: [Wi0(t,in0), Wi0(t,in1), Wi1(0,t), Wi1(1,t)], then
-                        per hidden tile t of [Wd0]: [Wd0(t,in0), Wd0(t,in1), Wd1(0,t)] — 40 tiles; when present the
-                        kernel forms fp32-accurate products on the bf16 cores */
+  const void* Wx;    /* optional bf16-core image (gn_split_bf16_f32) of the hidden-tile-major fp32 stream of the four
+                        layers — per hidden tile t of init_MLP: [Wi0(t,in0), Wi0(t,in1), Wi1(0,t), Wi1(1,t)], then
+                        per hidden tile t of [Wd0]: [Wd0(t,in0), Wd0(t,in1), Wd1(0,t)] — 40 tiles = 80 sub-steps.
+                        With it W may be NULL. */
 } gn_edge_group_t;
 int gn_edge_mlp_gumbel_f32(const gn_edge_group_t* groups, int n_groups, float tau, unsigned long long seed,
                            const unsigned long long* offset_dev, gn_stream_t stream);
+int gn_edge_mlp_gumbel_bf16(const gn_edge_group_t* groups, int n_groups, float tau, unsigned long long seed,
+                            const unsigned long long* offset_dev, gn_stream_t stream);
 
 /* ---- A5: hyperedge aggregation --------------------------------------------------------------
  * gather: eo = H ori            (edge_aggregation.forward, MS_HGNN_batch.py:263)
  * H == NULL: pairwise graph (E = N*N), eo[(i,j)] = ori_i + ori_j; with sym = 1 only the
  * E = N(N+1)/2 unordered pairs.   ori (B,N,64) -> eo (B,E,64). */
 typedef struct {
-  const float* ori;
+  const float* ori;   /* [T] */
   const float* H;
-  float* eo;
+  float* eo;          /* [T] */
   int E;
   int sym;
 } gn_gather_group_t;
 int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, int B, int N, gn_stream_t stream);
+int gn_agg_gather_bf16(const gn_gather_group_t* groups, int n_groups, int B, int N, gn_stream_t stream);
 
 /* typed MLP: feat = sum_k edge_feat[:,k] * MLP^k_{64->128->64}(eo)   (MS_HGNN_batch.py:262,264-265)
  * W: for each type k the packed images [agg_mlp[k].layers.0 (128x64) | agg_mlp[k].layers.1 (64x128)],
@@ -249,35 +282,37 @@ int gn_agg_gather_f32(const gn_gather_group_t* groups, int n_groups, int B, int 
  * sum_k edge_feat[p,k] * (W2k relu(A[i,k] + A[j,k]) + b2k).  W then is, per type, the packed (64 x 128)
  * image re-ordered hidden-tile-major ((t, o) instead of (o, t)); b1 is unused. */
 typedef struct {
-  const float* eo;
+  const float* eo;     /* [T] */
   const float* edge_feat;
   const float* W;
   const float* b1;
   const float* b2;
-  float* feat;
+  float* feat;         /* [T] */
   int rows;
   int K;
-  const float* ori;
+  const float* ori;    /* [T] */
   const float* H;
   int E;
   int N;
   int sym;
   const float* A;
-  const void* W2x3;   /* optional, pair form: layer 2 of every type as three bf16 parts in the 32x32x16 operand
-                         order (gn_split_bf16x3_f32 of the W image).  When present the pair form forms its
-                         products from the six significant bf16 part-products — as accurate as fp32
-                         accumulation, twice the matrix rate */
-  const void* W12x3;  /* optional, two-layer form: the same for both layers, hidden-tile-major: per type and
+  const void* W2x;    /* optional, pair form (fp32 entry point only): bf16-core image of layer 2 of every type
+                         (gn_split_bf16_f32 of the hidden-tile-major W image, 16 sub-steps per type) */
+  const void* W12x;   /* optional, two-layer form: bf16-core image of both layers, hidden-tile-major: per type and
                          hidden tile o the tiles [W1k(o, in 0), W1k(o, in 1), W2k(out 0, o), W2k(out 1, o)]
-                         (gn_split_bf16x3_f32 of that fp32 stream) */
+                         (32 sub-steps per type).  With W2x / W12x, W may be NULL. */
 } gn_agg_group_t;
 int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream);
-/* Packed fp32 32x32 weight tiles (gn_pack_linear_f32 layout, n_tiles of 1024 floats) -> for every tile and
- * each of its two k-halves three bf16 parts (x = p1 + p2 + p3, 8 mantissa bits each) in the A-operand order
- * of v_mfma_f32_32x32x16_bf16: out[(((tile*2 + half)*3 + part)*64 + lane)*8 + j] (16-bit words), where
+/* twin: two-layer form only (eo, or the fused gather from ori) — a per-node first layer stored in bf16 would
+ * cost as much VALU / LDS work per pair as the layer itself costs on the bf16 cores */
+int gn_agg_mlp_bf16(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream);
+/* Packed fp32 32x32 weight tiles (gn_pack_linear_f32 layout, n_tiles of 1024 floats) -> bf16-core image: for
+ * every tile and each of its two k-halves (one "sub-step") `parts` bf16 parts in the A-operand order of
+ * v_mfma_f32_32x32x16_bf16: out[(((tile*2 + half)*parts + part)*64 + lane)*8 + j] (16-bit words), where
  * element j of lane (m, h) is the weight of output m and k-feature 16*half + (j&3) + 8*(j>>2) + 4*h — the
- * order in which a lane's accumulator registers hold those features. */
-int gn_split_bf16x3_f32(const float* packed, void* out, int n_tiles, gn_stream_t stream);
+ * order in which a lane's accumulator registers hold those features.  parts = 3: x = p1 + p2 + p3 (8 mantissa
+ * bits each, round to nearest: the fp32-accurate path); parts = 1: p1 = x rounded to bf16 (the bf16 twins). */
+int gn_split_bf16_f32(const float* packed, void* out, int n_tiles, int parts, gn_stream_t stream);
 
 /* ---- A5, pairwise graph, layer 1 hoisted to the nodes -----------------------------------------
  * For the pairwise graph the typed MLP's input row is eo = ori_i + ori_j, so its first layer is
@@ -294,15 +329,17 @@ int gn_node_linear_f32(const float* x, const float* W, const float* bias, float*
  * feat (B,E,64), ori (B,N,64) -> out (B,N,128).  H == NULL: pairwise (E = N*N); with sym = 1 feat
  * holds the E = N(N+1)/2 pair sums (see gn_edge_mlp_gumbel_f32) and node n adds the N pairs {n,j}. */
 typedef struct {
-  const float* feat;
+  const float* feat;   /* [T] */
   const float* H;
-  const float* ori;
-  float* out;
+  const float* ori;    /* [T] */
+  float* out;          /* [T] */
   int E;
   int sym;
 } gn_scatter_group_t;
 int gn_agg_scatter_f32(const gn_scatter_group_t* groups, int n_groups, int B, int N, float divisor,
                        gn_stream_t stream);
+int gn_agg_scatter_bf16(const gn_scatter_group_t* groups, int n_groups, int B, int N, float divisor,
+                        gn_stream_t stream);
 
 /* ---- A6 / generic two-layer MLP ---------------------------------------------------------------
  * y = W1 relu(W0 x + b0) + b1     (MLP.forward with one hidden layer, MS_HGNN_batch.py:220-229;
@@ -316,21 +353,27 @@ int gn_agg_scatter_f32(const gn_scatter_group_t* groups, int n_groups, int B, in
  * (H (B,E,N); H == NULL: the pairwise graph, E = N*N ordered edges or, sym = 1, E = N(N+1)/2 pair
  * sums) — so the (B,N,128) aggregate never exists in HBM.  rows must equal B*N. */
 typedef struct {
-  const float* x;
+  const float* x;      /* [T] */
   const float* W;
   const float* bias;
-  float* y;
-  const float* feat;
+  float* y;            /* [T] */
+  const float* feat;   /* [T] */
   const float* H;
-  const float* ori;
+  const float* ori;    /* [T] */
   int E;
   int sym;
   float* in_out;    /* optional (training): the MLP's input rows as evaluated (rows, din) — with the fused
                        scatter that is cat(H^T feat, ori)/N, which otherwise never exists in memory */
   float* hid_out;   /* optional (training): the hidden activations relu(W0 x + b0) (rows, dh) */
+  const void* Wx;   /* optional bf16-core image, hidden-tile-major: per hidden tile t the tiles
+                       [W0(t, in 0..din/32-1), W1(0..ceil(dout/32)-1, t)]; used when dout <= 64 (else the launch
+                       needs W).  With it W may be NULL. */
 } gn_mlp2_group_t;
 int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
                 int N, float divisor, gn_stream_t stream);
+/* twin: dout <= 64 */
+int gn_mlp2_bf16(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
+                 int N, float divisor, gn_stream_t stream);
 
 /* ---- backward (training) building blocks — SURVEY.md §8f rank 2 -------------------------------
  * train_hyper_nba.py:116 back-propagates through the two modules.  The backward of the path is
