@@ -209,20 +209,26 @@ class MLP_dict_softmax(nn.Module):
                     b0(t + 2)
             plan.alloc(2 * T)
             w_len = plan.size - w0
-            # hidden-tile-major stream of the same four layers (source of the three-bf16-part image): 40 tiles
+            # the same four layers in the pipeline order of the bf16-core kernel (source of its image): 40 tiles
             wh = plan.alloc(40 * T)
-            for t in range(4):
-                base = wh + 4 * t * T
-                plan.block(base, i0.weight, 2, r0=32 * t, rows=32)
-                plan.block(base + 2 * T, i1.weight, 1, r0=0, c0=32 * t, rows=32, cols=32)
-                plan.block(base + 3 * T, i1.weight, 1, r0=32, c0=32 * t, rows=32, cols=32)
-            for t in range(8):
-                base = wh + (16 + 3 * t) * T
-                plan.block(base, (d0 if t < 4 else f0).weight, 2, r0=32 * (t % 4), rows=32)
-                if t < 4:
-                    plan.block(base + 2 * T, d1.weight, 1, c0=32 * t, cols=32)
+            off = wh
+            for kind, t in ops.pipeline_order(4):
+                if kind == "A":
+                    plan.block(off, i0.weight, 2, r0=32 * t, rows=32)
                 else:
-                    plan.block(base + 2 * T, f1.weight, 1, c0=32 * (t - 4), cols=32, place_r=K)
+                    plan.block(off, i1.weight, 1, r0=0, c0=32 * t, rows=32, cols=32)
+                    plan.block(off + T, i1.weight, 1, r0=32, c0=32 * t, rows=32, cols=32)
+                off += 2 * T
+            for kind, t in ops.pipeline_order(8):
+                if kind == "A":
+                    plan.block(off, (d0 if t < 4 else f0).weight, 2, r0=32 * (t % 4), rows=32)
+                    off += 2 * T
+                else:
+                    if t < 4:
+                        plan.block(off, d1.weight, 1, c0=32 * t, cols=32)
+                    else:
+                        plan.block(off, f1.weight, 1, c0=32 * (t - 4), cols=32, place_r=K)
+                    off += T
             bo = plan.alloc(128 + 64 + 256 + 32)
             plan.vector(bo, i0.bias)
             plan.vector(bo + 128, i1.bias)
@@ -289,11 +295,14 @@ class edge_aggregation(nn.Module):
             b1o, b2o, bho = plan.alloc(K * 128), plan.alloc(K * 64), plan.alloc(K * 128)
             w1c, w2t, w12 = plan.alloc(K * 8 * T), plan.alloc(K * 8 * T), plan.alloc(K * 16 * T)
             for k in range(K):
-                for o in range(4):      # hidden-tile-major image of both layers (source of the bf16x3 image)
-                    base = w12 + (k * 16 + o * 4) * T
-                    plan.block(base, l0[k].weight, 2, r0=32 * o, rows=32)
-                    plan.block(base + 2 * T, l1[k].weight, 1, r0=0, c0=32 * o, rows=32, cols=32)
-                    plan.block(base + 3 * T, l1[k].weight, 1, r0=32, c0=32 * o, rows=32, cols=32)
+                off = w12 + k * 16 * T  # both layers in the pipeline order of the bf16-core kernel (its image's source)
+                for kind, o in ops.pipeline_order(4):
+                    if kind == "A":
+                        plan.block(off, l0[k].weight, 2, r0=32 * o, rows=32)
+                    else:
+                        plan.block(off, l1[k].weight, 1, r0=0, c0=32 * o, rows=32, cols=32)
+                        plan.block(off + T, l1[k].weight, 1, r0=32, c0=32 * o, rows=32, cols=32)
+                    off += 2 * T
                 plan.vector(b1o + 128 * k, l0[k].bias)
                 plan.vector(b2o + 64 * k, l1[k].bias)
                 plan.vector(bho + 128 * k, l0[k].bias, scale=0.5)
@@ -344,7 +353,22 @@ def _volatile(params: Iterable[nn.Parameter]) -> bool:
     While autograd is recording for these parameters (a training step) every call therefore re-runs the one
     refresh launch of its pack plan; only inference (no-grad / frozen parameters) trusts the cache, and code
     that rewrites weights there behind autograd's back calls `invalidate_weight_caches`."""
-    return torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    return _TRAINING_CALL[0] or (torch.is_grad_enabled() and any(p.requires_grad for p in params))
+
+
+_TRAINING_CALL = [False]
+
+
+class training_call:
+    """Context of a forward that belongs to a training step (`backward.MSHGNNFunction.forward` runs under
+    no_grad, so `_volatile` cannot see it from the grad mode)."""
+
+    def __enter__(self):
+        self.prev, _TRAINING_CALL[0] = _TRAINING_CALL[0], True
+
+    def __exit__(self, *exc):
+        _TRAINING_CALL[0] = self.prev
+        return False
 
 
 def invalidate_weight_caches(module: nn.Module) -> None:
@@ -415,15 +439,18 @@ class _MessagePassing(nn.Module):
             plan.block(wpq, a0.weight, 2, c0=0, cols=D)
             plan.block(wpq, a0.weight, 2, c0=D, cols=D, place_r=32)
             w_len = plan.size - w0
-            # the same chain hidden-tile-major (source of the bf16-core image): per hidden tile t of layer 0 the
-            # tiles [W0(t,in0), W0(t,in1), W1(0,t), W1(1,t)], then Wpq as above: 36 tiles = 72 sub-steps
+            # the same chain in the pipeline order of the bf16-core kernel (source of its image): A_t = [W0(t,in0),
+            # W0(t,in1)], B_t = [W1(0,t), W1(1,t)], then Wpq as above: 36 tiles = 72 sub-steps
             T = plan.TILE
             wc = plan.alloc(36 * T)
-            for t in range(8):
-                base = wc + 4 * t * T
-                plan.block(base, s0.weight, 2, r0=32 * t, rows=32)
-                plan.block(base + 2 * T, s1.weight, 1, r0=0, c0=32 * t, rows=32, cols=32)
-                plan.block(base + 3 * T, s1.weight, 1, r0=32, c0=32 * t, rows=32, cols=32)
+            off = wc
+            for kind, t in ops.pipeline_order(8):
+                if kind == "A":
+                    plan.block(off, s0.weight, 2, r0=32 * t, rows=32)
+                else:
+                    plan.block(off, s1.weight, 1, r0=0, c0=32 * t, rows=32, cols=32)
+                    plan.block(off + T, s1.weight, 1, r0=32, c0=32 * t, rows=32, cols=32)
+                off += 2 * T
             plan.block(wc + 32 * T, a0.weight, 2, c0=0, cols=D)
             plan.block(wc + 32 * T, a0.weight, 2, c0=D, cols=D, place_r=32)
             bo = plan.alloc(256 + 64 + 64)
@@ -458,16 +485,20 @@ class _MessagePassing(nn.Module):
             xi = ops.XImages()
             wh = n_t = 0
             if dout <= 64 and din % 32 == 0 and dh % 32 == 0:
-                # hidden-tile-major (source of the bf16-core image): per hidden tile t [W0(t, in *), W1(*, t)]
+                # pipeline order of the bf16-core kernel (source of its image): A_t = W0(t, in *), B_t = W1(*, t)
                 T, IT, HT, OT = plan.TILE, din // 32, dh // 32, (dout + 31) // 32
                 n_t = HT * (IT + OT)
                 wh = plan.alloc(n_t * T)
-                for t in range(HT):
-                    base = wh + t * (IT + OT) * T
-                    plan.block(base, l0.weight, IT, r0=32 * t, rows=32)
-                    for o in range(OT):
-                        plan.block(base + (IT + o) * T, l1.weight, 1, r0=32 * o, c0=32 * t, rows=min(32, dout - 32 * o),
-                                   cols=32)
+                off = wh
+                for kind, t in ops.pipeline_order(HT):
+                    if kind == "A":
+                        plan.block(off, l0.weight, IT, r0=32 * t, rows=32)
+                        off += IT * T
+                    else:
+                        for o in range(OT):
+                            plan.block(off + o * T, l1.weight, 1, r0=32 * o, c0=32 * t, rows=min(32, dout - 32 * o),
+                                       cols=32)
+                        off += OT * T
             bo = plan.alloc(pad(dh) + pad(dout))
             plan.vector(bo, l0.bias)
             plan.vector(bo + pad(dh), l1.bias)

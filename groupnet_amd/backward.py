@@ -176,14 +176,12 @@ def _round_layers(mod, j: int):
 def _bwd_weights(mod, j: int) -> dict:
     """The concatenated weight matrices round j's backward GEMMs read — the K typed MLPs as one wide layer,
     MLP_distribution | MLP_factor side by side, the split attention layer 0 — assembled from the parameters
-    by ONE `PackPlan` launch per parameter version (no torch.cat, capturable)."""
+    by ONE `PackPlan` launch (no torch.cat, capturable).  A backward is by definition part of a training
+    step, where parameters may have been rewritten through `.data` without a version bump: the plan (arena and
+    segment table) is cached per parameter addresses, its one refresh launch runs on every call."""
     from .MS_HGNN_batch import _param_key
     cache = mod.__dict__.setdefault("_bwd_cat", {})
     hit = cache.get(j)
-    if (hit is not None and hit[3] is not None and hit[3] == _param_key(hit[4])
-            and mod.attention_mlp[j].layers[0].weight is hit[4][0]
-            and mod.edge_aggregation_list[j].agg_mlp[-1].layers[1].bias is hit[4][-1]):
-        return hit[1]           # same parameter objects, addresses and versions as at the last refresh
     (s0, s1), (a0, a1), st, agg, _ = _round_layers(mod, j)
     d0, d1 = st.MLP_distribution.layers
     f0, f1 = st.MLP_factor.layers
@@ -220,10 +218,8 @@ def _bwd_weights(mod, j: int) -> dict:
         cat = {n: plan.view(off[n], math.prod(shp)).view(*shp) for n, shp in shapes.items()}
         hit = cache[j] = [ptrs, cat, plan, None, params]
     hit[4] = params
-    key = _param_key(params)
-    if key != hit[3]:
-        hit[2].refresh()
-        hit[3] = key
+    hit[2].refresh()
+    hit[3] = _param_key(params)
     return hit[1]
 
 
@@ -450,14 +446,16 @@ class MSHGNNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mods, Hs, noises, *tensors):
-        from .MS_HGNN_batch import run_message_passing
+        from . import MS_HGNN_batch as M
         n = len(mods)
         hs, params = tensors[:n], tensors[n:]
         traces = [ModuleTrace(m, h.detach(), H) for m, h, H in zip(mods, hs, Hs)]
-        with torch.no_grad():
-            res = run_message_passing(list(mods), [t.xs[0] for t in traces], list(Hs), list(noises), [None] * n,
-                                      traces=traces)
+        with torch.no_grad(), M.training_call():     # a training step: packed-weight caches are not trusted
+            res = M.run_message_passing(list(mods), [t.xs[0] for t in traces], list(Hs), list(noises), [None] * n,
+                                        traces=traces)
         ctx.traces, ctx.params, ctx.n = traces, params, n
+        # the backward reads the LIVE weights (and re-packs them): remember which versions the activations belong to
+        ctx.param_key = M._param_key(params)
         out = []
         for nf, fac in res:
             out += [nf, fac]
@@ -465,6 +463,11 @@ class MSHGNNFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        from .MS_HGNN_batch import _param_key
+        if _param_key(ctx.params) != ctx.param_key:
+            raise RuntimeError("one of the parameters of an MS-HGNN module was modified in place between the forward and "
+                               "this backward (e.g. an optimizer step before backward()): the saved activations belong "
+                               "to the old weights.  torch's own autograd raises here too.")
         n = ctx.n
         g_nfs = [None if g is None else g.contiguous() for g in gs[0::2]]
         g_facs = [None if g is None else g.contiguous() for g in gs[1::2]]

@@ -28,6 +28,21 @@
 #pragma once
 #include "gn_mlp_common.hpp"
 
+#ifdef GN_STAMPS
+// Diagnostic build only (never the product): per-wave cycle stamps, read back with gn_debug_read_stamps.
+__device__ unsigned long long gn_stamp_buf[1 << 17];
+#define GN_STAMP(unit, slot)                                                              \
+  do {                                                                                    \
+    if ((threadIdx.x & 63) == 0 && (unit) < (1 << 13))                                    \
+      gn_stamp_buf[(size_t)(unit) * 16 + (slot)] = ((slot) & 8) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int gn_debug_read_stamps(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gn_stamp_buf), bytes);
+}
+#else
+#define GN_STAMP(unit, slot) do {} while (0)
+#endif
+
 namespace {
 
 template <int P>
@@ -62,7 +77,10 @@ __device__ __forceinline__ void make_parts_tiles(const f32x16 (&v)[NT], Parts<P>
 
 template <int P>
 struct XRing {
-  static constexpr int D = P == 3 ? 4 : 16;   // ring depth in sub-steps
+#ifndef GN_RING3
+#define GN_RING3 4
+#endif
+  static constexpr int D = P == 3 ? GN_RING3 : 16;   // ring depth in sub-steps
   f32x4 q[D * P];
   __device__ __forceinline__ void prime(const f32x4* __restrict__ src) {   // src: this lane's pointer at sub-step 0
 #pragma unroll
@@ -70,6 +88,9 @@ struct XRing {
   }
   // acc += W[sub-step in ring slot s % D] . x, then the slot is refilled from `next` (this lane's pointer at the
   // sub-step D ahead).  `s` must be a compile-time constant at every call site (fully unrolled callers).
+  // FENCE: close the scheduling region behind the step (the default); a caller that interleaves other work with a
+  // run of steps passes false and fences the run itself.
+  template <bool FENCE = true>
   __device__ __forceinline__ void step(int s, const Parts<P>& x, f32x16& acc, const f32x4* __restrict__ next) {
     const int u = (s % D) * P;
     if constexpr (P == 3) {
@@ -85,12 +106,78 @@ struct XRing {
     } else {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q[u]), x.p[0], acc, 0, 0, 0);
     }
+#ifndef GN_NO_REFILL     // (diagnostic builds only: what the kernels would take with the weights already in registers)
 #pragma unroll
     for (int p = 0; p < P; ++p) q[u + p] = next[p * 64];
+#endif
     // hipcc otherwise sinks the run-ahead loads down to their use and collapses the ring
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
   }
 };
+
+// ---- one layer pair, hidden tile by hidden tile, software-pipelined ------------------------------------------------
+//   out[o] += W1(o, :) post(W0 x + b0)      x: IT input tiles (as parts), HT hidden tiles, OT output tiles
+// A_t = the 2*IT sub-steps that produce hidden tile t, V_t = its VALU work (post: ReLU / scale / optional store,
+// then the bf16 part(s)), B_t = the 2*OT sub-steps that consume it.  B_t needs V_t needs A_t, so executed in that
+// order a lone wave leaves the matrix pipe idle during every V_t (~120 VALU instructions for three parts).  The
+// pipeline issues A_{t+1} between A_t and B_t and interleaves V_t with its MFMAs (sched_group_barrier: one MFMA,
+// then a few VALU), so the splitting runs in the shadow of the matrix pipe.  The weight image is laid out in this
+// order:  A0 A1 B0 A2 B1 ... A(HT-1) B(HT-2) B(HT-1).  Bias tiles ride two hidden tiles ahead of their use: a
+// load that is waited for right after it is issued would also wait for every run-ahead load of the weight ring
+// (vmcnt counts in order).
+//   pos0: stream position (sub-steps) of A0 — a compile-time constant at the call site; nxt(pos): this lane's
+//   pointer at position pos + D;  hid0: bias tile 0 (loaded early by the caller).
+template <int P, int IT, int OT, int HT, typename NextFn, typename PostFn>
+__device__ __forceinline__ void layer_pair(XRing<P>& ring, int pos0, NextFn nxt, const Parts<P> (&xi)[IT][2],
+                                           const f32x16& hid0, const float* __restrict__ b0, int h,
+                                           f32x16 (&out)[OT], PostFn post) {
+  constexpr int NA = 2 * IT, NB = 2 * OT;
+  constexpr int kMfma = NA * (P == 3 ? 6 : 1);                 // MFMAs of one A phase
+#ifndef GN_KVALU
+#define GN_KVALU 96
+#endif
+  constexpr int kValu = P == 3 ? (GN_KVALU + kMfma - 1) / kMfma : (40 + kMfma - 1) / kMfma;   // VALU slots per MFMA
+  int pos = pos0;
+  f32x16 hidn = hid0;
+  f32x16 bias_n;
+  if (HT > 1) bias_n = load_bias_tile(b0 + 32, h);
+#pragma unroll
+  for (int u = 0; u < NA; ++u) {
+    ring.step(pos, xi[u >> 1][u & 1], hidn, nxt(pos));
+    ++pos;
+  }
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    f32x16 cur = hidn;
+    if (t + 1 < HT) {
+      hidn = bias_n;
+      if (t + 2 < HT) bias_n = load_bias_tile(b0 + 32 * (t + 2), h);
+    }
+    post(t, cur);
+    Parts<P> xh[2];
+    make_parts<P>(cur, 0, xh[0]);
+    make_parts<P>(cur, 1, xh[1]);
+    if (t + 1 < HT) {
+#pragma unroll
+      for (int u = 0; u < NA; ++u) {
+        ring.template step<false>(pos, xi[u >> 1][u & 1], hidn, nxt(pos));
+        ++pos;
+      }
+#pragma unroll
+      for (int i = 0; i < kMfma; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);      // VALU of V_t in its shadow
+        if (P == 3 ? (i & 1) == 1 : true) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a ring refill
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      ring.step(pos, xh[u & 1], out[u >> 1], nxt(pos));
+      ++pos;
+    }
+  }
+}
 
 template <typename T>
 __device__ __forceinline__ void store_tile(T* __restrict__ p, const f32x16& a) {   // p: row base + 32*tile + 4*h
@@ -123,45 +210,37 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
     const int gi = gn_uniform(unit / Tb.blocks32);
     const gn_node_group_t G = Tb.g[gi];
     const RowBlock rb = row_block(Tb.rows, unit - gi * Tb.blocks32);
-    f32x16 in[2];
-    load_rows<2>(reinterpret_cast<const T*>(G.x), GN_FEAT, rb.row_ld, h, in);
-    Parts<P> xi[2][2];
-    make_parts_tiles<P, 2>(in, xi);
+    GN_STAMP(unit, 0);
+    GN_STAMP(unit, 8);
     const float* b0 = G.bias;
     const float* b1 = G.bias + 256;
     const float* bpq = G.bias + 320;
     const f32x4* Wx = reinterpret_cast<const f32x4*>(G.Wx) + lane;
     XRing<P> ring;
     ring.prime(Wx);
-    constexpr int kSub = 72;
-    auto nxt = [&](int s) { return Wx + (size_t)(s + D < kSub ? s + D : s + D - kSub) * P * 64; };
-    f32x16 xp[2];
+    f32x16 in[2];
+    load_rows<2>(reinterpret_cast<const T*>(G.x), GN_FEAT, rb.row_ld, h, in);
+    const f32x16 hid0 = load_bias_tile(b0, h);
+    f32x16 xp[2], pq[2];
     xp[0] = load_bias_tile(b1, h);
     xp[1] = load_bias_tile(b1 + 32, h);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      f32x16 hid = load_bias_tile(b0 + 32 * t, h);
-      const int s = 8 * t;
-      ring.step(s + 0, xi[0][0], hid, nxt(s + 0));
-      ring.step(s + 1, xi[0][1], hid, nxt(s + 1));
-      ring.step(s + 2, xi[1][0], hid, nxt(s + 2));
-      ring.step(s + 3, xi[1][1], hid, nxt(s + 3));
+    pq[0] = load_bias_tile(bpq, h);
+    pq[1] = load_bias_tile(bpq + 32, h);
+    Parts<P> xi[2][2];
+    make_parts_tiles<P, 2>(in, xi);
+    GN_STAMP(unit, 1);
+    constexpr int kSub = 72;
+    auto nxt = [&](int s) { return Wx + (size_t)(s + D < kSub ? s + D : s + D - kSub) * P * 64; };
+    // image: the 64->256->64 pair in pipeline order (A_t = [W0(t,in0), W0(t,in1)], B_t = [W1(0,t), W1(1,t)]), then
+    // [Wpq(0,in0), Wpq(0,in1), Wpq(1,in0), Wpq(1,in1)]
+    layer_pair<P, 2, 2, 8>(ring, 0, nxt, xi, hid0, b0, h, xp, [&](int t, f32x16& hid) {
       relu16(hid);
       if (G.hid_out != nullptr && rb.live) store_tile(G.hid_out + (size_t)rb.row * 256 + 32 * t + 4 * h, hid);
-      Parts<P> xh[2];
-      make_parts<P>(hid, 0, xh[0]);
-      make_parts<P>(hid, 1, xh[1]);
-      ring.step(s + 4, xh[0], xp[0], nxt(s + 4));
-      ring.step(s + 5, xh[1], xp[0], nxt(s + 5));
-      ring.step(s + 6, xh[0], xp[1], nxt(s + 6));
-      ring.step(s + 7, xh[1], xp[1], nxt(s + 7));
-    }
+    });
+    GN_STAMP(unit, 2);
     store_rows<2>(reinterpret_cast<T*>(G.xp), GN_FEAT, rb.row, h, rb.live, xp);
     Parts<P> xq[2][2];
     make_parts_tiles<P, 2>(xp, xq);
-    f32x16 pq[2];
-    pq[0] = load_bias_tile(bpq, h);
-    pq[1] = load_bias_tile(bpq + 32, h);
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
       const int s = 64 + 4 * o;
@@ -170,7 +249,10 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
       ring.step(s + 2, xq[1][0], pq[o], nxt(s + 2));
       ring.step(s + 3, xq[1][1], pq[o], nxt(s + 3));
     }
+    GN_STAMP(unit, 3);
     store_rows<2>(reinterpret_cast<T*>(G.pq), GN_FEAT, rb.row, h, rb.live, pq);
+    GN_STAMP(unit, 4);
+    GN_STAMP(unit, 9);
     return;
   }
   // ---- A unit ----
@@ -184,10 +266,13 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
   const int local = v - Tb.a_first[gi];
   const int blk = local / chunks, c = local - blk * chunks;
   const RowBlock rb = row_block(Tb.rows, blk);
+  GN_STAMP(unit, 0);
+  GN_STAMP(unit, 8);
   f32x16 in[2];
   load_rows<2>(reinterpret_cast<const T*>(G.x), GN_FEAT, rb.row_ld, h, in);
   Parts<P> xi[2][2];
   make_parts_tiles<P, 2>(in, xi);
+  GN_STAMP(unit, 1);
   const int o0 = c * kATiles;
   const int nt = min(kATiles, OTA - o0);                 // a multiple of 4
   const int nsub = 4 * nt;
@@ -196,12 +281,14 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
   ring.prime(Wa);
   const size_t ldA = (size_t)OTA * 32;
   T* arow = reinterpret_cast<T*>(G.A) + (size_t)rb.row * ldA + 4 * h;
+  f32x16 bn = load_bias_tile(G.bA + 32 * o0, h);          // bias rides one tile ahead (see layer_pair)
 #pragma unroll 1
   for (int o4 = 0; o4 < nt; o4 += 4) {
 #pragma unroll
     for (int oo = 0; oo < 4; ++oo) {
       const int o = o0 + o4 + oo;
-      f32x16 acc = load_bias_tile(G.bA + 32 * o, h);
+      f32x16 acc = bn;
+      bn = load_bias_tile(G.bA + 32 * min(o + 1, o0 + nt - 1), h);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int s = 4 * oo + i;                        // ring slot: 16 sub-steps per iteration of the outer loop
@@ -211,6 +298,8 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
       if (rb.live) store_tile(arow + 32 * o, acc);
     }
   }
+  GN_STAMP(unit, 4);
+  GN_STAMP(unit, 9);
 }
 
 // ---- A4: z = MLP(64->128->64); [dist|fac] heads; gumbel softmax; sigmoid -------------------------------------
@@ -228,6 +317,9 @@ __global__ __launch_bounds__(256, 2) void edge_x_kernel(GroupTable<gn_edge_group
   if (blk * 32 >= rows) return;
   const RowBlock rb = row_block(rows, blk);
   const int lane = rb.lane, h = rb.h;
+  const int unit = blockIdx.x * 4 + wave_id();
+  GN_STAMP(unit, 0);
+  GN_STAMP(unit, 8);
   f32x16 in[2], z[2], lg;
   load_rows<2>(reinterpret_cast<const T*>(G.edges), GN_FEAT, rb.row_ld, h, in);
   // ordered edge rows whose uniforms this row consumes: itself, or — symmetric pairwise form — the two ordered
@@ -245,10 +337,6 @@ __global__ __launch_bounds__(256, 2) void edge_x_kernel(GroupTable<gn_edge_group
   }
   float u1[8], u2[8];
   const unsigned long long pbase = G.philox_offset + (offset_dev ? *offset_dev : 0ull);
-  if (G.U != nullptr) {
-    fetch_uniforms(G.U, 0ull, 0ull, o1, K, h, u1);
-    if (G.sym_N > 0) fetch_uniforms(G.U, 0ull, 0ull, o2, K, h, u2);
-  }
   const float* bi0 = G.bias;
   const float* bi1 = G.bias + 128;
   const float* bd0 = G.bias + 192;
@@ -258,53 +346,33 @@ __global__ __launch_bounds__(256, 2) void edge_x_kernel(GroupTable<gn_edge_group
   ring.prime(Wx);
   constexpr int kSub = 80;
   auto nxt = [&](int s) { return Wx + (size_t)(s + D < kSub ? s + D : s + D - kSub) * P * 64; };
-  Parts<P> xi[2][2];
-  make_parts_tiles<P, 2>(in, xi);
+  const f32x16 hidA0 = load_bias_tile(bi0, h);
+  const f32x16 hidB0 = load_bias_tile(bd0, h);
   z[0] = load_bias_tile(bi1, h);
   z[1] = load_bias_tile(bi1 + 32, h);
-  lg = load_bias_tile(bd1, h);
-  // ---- pair A: 4 hidden tiles x (4 + 4) sub-steps ----
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    f32x16 hid = load_bias_tile(bi0 + 32 * t, h);
-    const int s = 8 * t;
-    ring.step(s + 0, xi[0][0], hid, nxt(s + 0));
-    ring.step(s + 1, xi[0][1], hid, nxt(s + 1));
-    ring.step(s + 2, xi[1][0], hid, nxt(s + 2));
-    ring.step(s + 3, xi[1][1], hid, nxt(s + 3));
+  f32x16 lgv[1];
+  lgv[0] = load_bias_tile(bd1, h);
+  Parts<P> xi[2][2];
+  make_parts_tiles<P, 2>(in, xi);
+  GN_STAMP(unit, 1);
+  // ---- pair A: 64 -> 128 -> 64, 4 hidden tiles x (4 + 4) sub-steps, pipeline order ----
+  layer_pair<P, 2, 2, 4>(ring, 0, nxt, xi, hidA0, bi0, h, z, [&](int t, f32x16& hid) {
     relu16(hid);
     if (G.keep_z1 != nullptr && rb.live) store_tile(G.keep_z1 + (size_t)rb.row * 128 + 32 * t + 4 * h, hid);
-    Parts<P> xh[2];
-    make_parts<P>(hid, 0, xh[0]);
-    make_parts<P>(hid, 1, xh[1]);
-    ring.step(s + 4, xh[0], z[0], nxt(s + 4));
-    ring.step(s + 5, xh[1], z[0], nxt(s + 5));
-    ring.step(s + 6, xh[0], z[1], nxt(s + 6));
-    ring.step(s + 7, xh[1], z[1], nxt(s + 7));
-  }
+  });
+  GN_STAMP(unit, 2);
   if (G.keep_z != nullptr) store_rows<2>(G.keep_z, GN_FEAT, rb.row, h, rb.live, z);
   make_parts_tiles<P, 2>(z, xi);
-  // ---- pair B: 8 hidden tiles x (4 + 2) sub-steps ----
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    f32x16 hid = load_bias_tile(bd0 + 32 * t, h);
-    const int s = 32 + 6 * t;
-    ring.step(s + 0, xi[0][0], hid, nxt(s + 0));
-    ring.step(s + 1, xi[0][1], hid, nxt(s + 1));
-    ring.step(s + 2, xi[1][0], hid, nxt(s + 2));
-    ring.step(s + 3, xi[1][1], hid, nxt(s + 3));
+  // ---- pair B: 64 -> 256 -> (logits | factor), 8 hidden tiles x (4 + 2) sub-steps, pipeline order ----
+  layer_pair<P, 2, 1, 8>(ring, 32, nxt, xi, hidB0, bd0, h, lgv, [&](int t, f32x16& hid) {
     relu16(hid);
     if (G.keep_dh1 != nullptr && rb.live) store_tile(G.keep_dh1 + (size_t)rb.row * 256 + 32 * t + 4 * h, hid);
-    Parts<P> xh[2];
-    make_parts<P>(hid, 0, xh[0]);
-    make_parts<P>(hid, 1, xh[1]);
-    ring.step(s + 4, xh[0], lg, nxt(s + 4));
-    ring.step(s + 5, xh[1], lg, nxt(s + 5));
-  }
-  if (G.U == nullptr) {
-    fetch_uniforms(nullptr, pbase, seed, o1, K, h, u1);
-    if (G.sym_N > 0) fetch_uniforms(nullptr, pbase, seed, o2, K, h, u2);
-  }
+  });
+  lg = lgv[0];
+  GN_STAMP(unit, 3);
+  // uniforms: read from U or generated from the Philox stream — after the chains (nothing is in flight any more)
+  fetch_uniforms(G.U, pbase, seed, o1, K, h, u1);
+  if (G.sym_N > 0) fetch_uniforms(G.U, pbase, seed, o2, K, h, u2);
   if (G.keep_lgf != nullptr && rb.live) store_tile(G.keep_lgf + (size_t)rb.row * 32 + 4 * h, lg);
 
   // Epilogue.  Features 0..K-1 of `lg` are the logits of this lane's row, feature K the factor pre-activation; a
@@ -346,6 +414,8 @@ __global__ __launch_bounds__(256, 2) void edge_x_kernel(GroupTable<gn_edge_group
       }
     }
   }
+  GN_STAMP(unit, 4);
+  GN_STAMP(unit, 9);
 }
 
 // ---- A5 typed MLP on the bf16 cores: feat = sum_k ef[:,k] * (W2k relu(W1k eo + b1k) + b2k) -----------------------
@@ -367,7 +437,7 @@ __device__ __forceinline__ void add_b2(const float* __restrict__ b2k, float efk,
 template <int P, typename T>
 __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) {
   constexpr int D = XRing<P>::D;
-  __shared__ float part[4][32][64];   // wpr > 1: [wave][register 0..31][lane]; staged pair form: node rows
+  __shared__ float part[4][32][64 + 8];   // wpr > 1: [wave][register 0..31][lane]; staged pair form: 2 x node rows
   const int gi = find_group(Tb, blockIdx.x);
   const gn_agg_group_t G = Tb.g[gi].a;
   const int wpr = Tb.g[gi].wpr;
@@ -390,11 +460,16 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
   const float* b1 = G.b1;
   const float* b2 = G.b2;
   XRing<P> ring;
+  const int unit = blockIdx.x * 4 + wave;
+  GN_STAMP(unit, 0);
+  GN_STAMP(unit, 8);
 
   bool pair_form = false;
   if constexpr (P == 3) pair_form = G.A != nullptr;
   if (pair_form) {
-    // ---- pair form ---------------------------------------------------------------------------------------------
+    // ---- pair form: hid_t = relu(A_i + A_j) * ef_k is VALU work (V_t), its layer-2 slice the matrix work (B_t).
+    // Pipelined: V of the NEXT tile (the next type's tile 0 after t == 3) is interleaved with the MFMAs of B_t, the
+    // pre-activations it needs were loaded one tile earlier still.
     const int N = G.N, Pn = G.E;
     int i, j;
     {
@@ -406,77 +481,98 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
     const size_t ldA = (size_t)K * 128;
     const T* Abase = reinterpret_cast<const T*>(G.A);
     const f32x4* Wx = reinterpret_cast<const f32x4*>(G.W2x) + lane;   // sub-step s of type k: (k*16 + s)
-    // one hidden tile: relu(A_i + A_j) * ef_k -> both output tiles (4 sub-steps)
-    auto tile = [&](int t, const PreTile& pa, const PreTile& pb, float efk, const f32x4* cur, const f32x4* nx) {
+    auto hidden = [&](const PreTile& pa, const PreTile& pb, float efk, Parts<P> (&xh)[2]) {
       f32x16 hid;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c) hid[4 * q + c] = fmaxf(pa.v[q][c] + pb.v[q][c], 0.f) * efk;
-      Parts<P> xh[2];
       make_parts<P>(hid, 0, xh[0]);
       make_parts<P>(hid, 1, xh[1]);
+    };
+    // B_t with the next tile's V in its shadow
+    auto slice = [&](int t, const Parts<P> (&xh)[2], const f32x4* cur, const f32x4* nx, const PreTile& pa,
+                     const PreTile& pb, float ef_next, Parts<P> (&xh_next)[2]) {
+      hidden(pa, pb, ef_next, xh_next);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int s = 4 * t + u;                      // [W2(0,t) hf0, hf1, W2(1,t) hf0, hf1]
         const f32x4* src = s + D < 16 ? cur + (size_t)(s + D) * P * 64 : nx + (size_t)(s + D - 16) * P * 64;
-        ring.step(s, xh[u & 1], out[u >> 1], src);
+        ring.template step<false>(s, xh[u & 1], out[u >> 1], src);
       }
+#pragma unroll
+      for (int m = 0; m < 24; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        if (m & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     };
     if (staged) {
       // The 4 row blocks of this workgroup touch a short run of consecutive node rows: the workgroup copies that
-      // run (one type at a time, coalesced, prefetched in registers under the previous type's MFMAs) into LDS.
+      // run (one type at a time, coalesced, prefetched in registers a type ahead) into one of two LDS buffers.
       float* stage = &part[0][0][0];
       const int r0 = wg * 128, r1 = min(rows - 1, r0 + 127);
       const int node0 = (r0 / Pn) * N;
       const int nodes = (r1 / Pn + 1) * N - node0;
       const f32x4* Ag = reinterpret_cast<const f32x4*>(Abase + (size_t)node0 * ldA);
       const int total4 = nodes * 32;                      // 16-byte pieces per type (fp32 storage)
-      f32x4 pre[kStageLoads];
+      f32x4 pre[kStageLoadsX];
       auto fetch = [&](int kk) {
 #pragma unroll
-        for (int it = 0; it < kStageLoads; ++it) {
+        for (int it = 0; it < kStageLoadsX; ++it) {
           const int idx = min((int)threadIdx.x + it * 256, total4 - 1);
           pre[it] = Ag[(size_t)(idx >> 5) * (ldA / 4) + kk * 32 + (idx & 31)];
         }
       };
-      auto commit = [&]() {
+      auto commit = [&](int buf) {
 #pragma unroll
-        for (int it = 0; it < kStageLoads; ++it) {
+        for (int it = 0; it < kStageLoadsX; ++it) {
           const int idx = (int)threadIdx.x + it * 256;
-          if (idx < total4) *reinterpret_cast<f32x4*>(stage + (idx >> 5) * kStagePitch + (idx & 31) * 4) = pre[it];
+          if (idx < total4)
+            *reinterpret_cast<f32x4*>(stage + buf * kStageBuf + (idx >> 5) * kStagePitch + (idx & 31) * 4) = pre[it];
         }
       };
-      const float* Si = stage + (i - node0) * kStagePitch;
-      const float* Sj = stage + (j - node0) * kStagePitch;
+      const int oi = (i - node0) * kStagePitch, oj = (j - node0) * kStagePitch;
       ring.prime(Wx);
       fetch(0);
-      commit();
+      commit(0);
+      fetch(K > 1 ? 1 : 0);
       __syncthreads();
-      PreTile pa = load_pre(Si, h), pb = load_pre(Sj, h);
       float efk = efrow[0];
+      Parts<P> xh[2];
+      PreTile pa = load_pre(stage + oi, h), pb = load_pre(stage + oj, h);
+      hidden(pa, pb, efk, xh);                            // V of (type 0, tile 0): the only exposed one
+      pa = load_pre(stage + oi + 32, h);
+      pb = load_pre(stage + oj + 32, h);
 #pragma unroll 1
       for (int k = 0; k < K; ++k) {
         const int kc = k + 1 < K ? k + 1 : k;
-        fetch(kc);                                        // next type's rows: in flight during this type's MFMAs
         const float efk_next = efrow[kc];
+        const float* cb = stage + (k & 1) * kStageBuf;        // this type's rows
+        const float* nb = stage + (kc & 1) * kStageBuf;       // the next type's
+        if (k + 1 < K) commit((k + 1) & 1);                   // (that buffer was last read during type k - 1)
+        if (k + 2 < K) fetch(k + 2);
         add_b2(b2 + k * 64, efk, lane, h, out);
         const f32x4* cur = Wx + (size_t)k * 16 * P * 64;
         const f32x4* nx = Wx + (size_t)kc * 16 * P * 64;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+          // pa/pb hold tile t+1 (tile 0 of the next type when t == 3); fetch the one after it
           const PreTile qa = pa, qb = pb;
-          if (t < 3) {
-            pa = load_pre(Si + 32 * (t + 1), h);
-            pb = load_pre(Sj + 32 * (t + 1), h);
+          if (t == 2) __syncthreads();                        // the next type's rows are committed by every wave
+          if (t < 2) {
+            pa = load_pre(cb + oi + 32 * (t + 2), h);
+            pb = load_pre(cb + oj + 32 * (t + 2), h);
+          } else {
+            pa = load_pre(nb + oi + 32 * (t - 2), h);
+            pb = load_pre(nb + oj + 32 * (t - 2), h);
           }
-          tile(t, qa, qb, efk, cur, nx);
+          Parts<P> xn[2];
+          slice(t, xh, cur, nx, qa, qb, t < 3 ? efk : efk_next, xn);
+          xh[0] = xn[0];
+          xh[1] = xn[1];
         }
-        __syncthreads();                                  // every wave has read type k's rows
-        commit();
-        __syncthreads();
-        pa = load_pre(Si, h);
-        pb = load_pre(Sj, h);
         efk = efk_next;
       }
       if (!any_rows) return;
@@ -485,8 +581,12 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
       const T* Aj = Abase + (size_t)j * ldA;
       int k = sub;
       ring.prime(Wx + (size_t)k * 16 * P * 64);
-      PreTile pa = load_pre(Ai + k * 128, h), pb = load_pre(Aj + k * 128, h);
       float efk = efrow[k];
+      Parts<P> xh[2];
+      PreTile pa = load_pre(Ai + k * 128, h), pb = load_pre(Aj + k * 128, h);
+      hidden(pa, pb, efk, xh);
+      pa = load_pre(Ai + k * 128 + 32, h);
+      pb = load_pre(Aj + k * 128 + 32, h);
 #pragma unroll 1
       while (k < K) {
         const int kn = k + wpr;
@@ -498,11 +598,13 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const PreTile qa = pa, qb = pb;
-          // the next tile's pre-activations (next type's tile 0 after t == 3) load under this tile's MFMAs
-          const int off = t < 3 ? k * 128 + 32 * (t + 1) : kc * 128;
+          const int off = t < 2 ? k * 128 + 32 * (t + 2) : kc * 128 + 32 * (t - 2);
           pa = load_pre(Ai + off, h);
           pb = load_pre(Aj + off, h);
-          tile(t, qa, qb, efk, cur, nx);
+          Parts<P> xn[2];
+          slice(t, xh, cur, nx, qa, qb, t < 3 ? efk : efk_next, xn);
+          xh[0] = xn[0];
+          xh[1] = xn[1];
         }
         efk = efk_next;
         k = kn;
@@ -518,10 +620,11 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
       gather_rows<T>(G, rb.row_ld, h, in);
     Parts<P> xi[2][2];
     make_parts_tiles<P, 2>(in, xi);
+    GN_STAMP(unit, 1);
     const f32x4* Wx = reinterpret_cast<const f32x4*>(G.W12x) + lane;   // sub-step s of type k: (k*32 + s)
     int k = sub;
     ring.prime(Wx + (size_t)k * 32 * P * 64);
-    f32x16 bnext = load_bias_tile(b1 + k * 128, h);
+    f32x16 hid0 = load_bias_tile(b1 + k * 128, h);
     float efk = efrow[k];
 #pragma unroll 1
     while (k < K) {
@@ -530,33 +633,22 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
       const f32x4* cur = Wx + (size_t)k * 32 * P * 64;
       const f32x4* nx = Wx + (size_t)kc * 32 * P * 64;
       const float efk_next = efrow[kc];
+      const f32x16 hid0_next = load_bias_tile(b1 + kc * 128, h);
       add_b2(b2 + k * 64, efk, lane, h, out);
       auto src = [&](int s) { return s + D < 32 ? cur + (size_t)(s + D) * P * 64 : nx + (size_t)(s + D - 32) * P * 64; };
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        f32x16 hid = bnext;
-        bnext = load_bias_tile(o < 3 ? b1 + k * 128 + 32 * (o + 1) : b1 + kc * 128, h);
-        const int s = 8 * o;
-        ring.step(s + 0, xi[0][0], hid, src(s + 0));
-        ring.step(s + 1, xi[0][1], hid, src(s + 1));
-        ring.step(s + 2, xi[1][0], hid, src(s + 2));
-        ring.step(s + 3, xi[1][1], hid, src(s + 3));
-        relu_scale16(hid, efk);
-        Parts<P> xh[2];
-        make_parts<P>(hid, 0, xh[0]);
-        make_parts<P>(hid, 1, xh[1]);
-        ring.step(s + 4, xh[0], out[0], src(s + 4));
-        ring.step(s + 5, xh[1], out[0], src(s + 5));
-        ring.step(s + 6, xh[0], out[1], src(s + 6));
-        ring.step(s + 7, xh[1], out[1], src(s + 7));
-      }
+      layer_pair<P, 2, 2, 4>(ring, 0, src, xi, hid0, b1 + k * 128, h, out,
+                             [&](int, f32x16& hid) { relu_scale16(hid, efk); });
+      hid0 = hid0_next;
       efk = efk_next;
       k = kn;
     }
   }
   T* feat = reinterpret_cast<T*>(G.feat);
+  GN_STAMP(unit, 2);
   if (wpr == 1) {
     store_rows<2>(feat, GN_FEAT, rb.row, h, rb.live, out);
+    GN_STAMP(unit, 4);
+    GN_STAMP(unit, 9);
     return;
   }
 #pragma unroll
@@ -582,13 +674,15 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
       st4(p + 32 * o + 8 * q, v);
     }
   }
+  GN_STAMP(unit, 4);
+  GN_STAMP(unit, 9);
 }
 
 // ---- A6 / closing MLP on the bf16 cores: y = W1 relu(W0 x + b0) + b1, dout <= 64 ---------------------------------
 // Image, hidden-tile-major: per hidden tile t the tiles [W0(t, in 0..IT-1), W1(0..OT-1, t)].  Input rows read from
 // x or formed on the fly (fused scatter, IT == 4) exactly as in mlp2_kernel.  blockIdx.y = group.
 template <int P, typename T, int IT, int HT, int OT>
-__global__ __launch_bounds__(256, 2) void mlp2_x_kernel(GroupTable<gn_mlp2_group_t> Tb, int rows, int dout, int ldy,
+__global__ __launch_bounds__(256, (P == 3 && IT == 4) ? 1 : 2) void mlp2_x_kernel(GroupTable<gn_mlp2_group_t> Tb, int rows, int dout, int ldy,
                                                         int N, float divisor) {
   constexpr int D = XRing<P>::D;
   const int blk = blockIdx.x * 4 + wave_id();
@@ -596,9 +690,18 @@ __global__ __launch_bounds__(256, 2) void mlp2_x_kernel(GroupTable<gn_mlp2_group
   const gn_mlp2_group_t G = Tb.g[blockIdx.y];
   const RowBlock rb = row_block(rows, blk);
   const int lane = rb.lane, h = rb.h;
+  const int unit = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave_id();
+  GN_STAMP(unit, 0);
+  GN_STAMP(unit, 8);
   const f32x4* Wx = reinterpret_cast<const f32x4*>(G.Wx) + lane;
   XRing<P> ring;
   ring.prime(Wx);
+  const float* b0 = G.bias;
+  const float* b1 = G.bias + 32 * HT;
+  const f32x16 hid0 = load_bias_tile(b0, h);
+  f32x16 out[OT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o) out[o] = load_bias_tile(b1 + 32 * o, h);
   Parts<P> xi[IT][2];
   {
     f32x16 in[IT];
@@ -606,31 +709,20 @@ __global__ __launch_bounds__(256, 2) void mlp2_x_kernel(GroupTable<gn_mlp2_group
     if (G.in_out != nullptr) store_rows<IT>(G.in_out, 32 * IT, rb.row, h, rb.live, in);   // kept for the backward
     make_parts_tiles<P, IT>(in, xi);
   }
-  constexpr int kPer = 2 * IT + 2 * OT, kSub = HT * kPer;
+  GN_STAMP(unit, 1);
+  constexpr int kSub = HT * (2 * IT + 2 * OT);
   auto nxt = [&](int s) { return Wx + (size_t)(s + D < kSub ? s + D : s + D - kSub) * P * 64; };
-  const float* b0 = G.bias;
-  const float* b1 = G.bias + 32 * HT;
-  f32x16 out[OT];
-#pragma unroll
-  for (int o = 0; o < OT; ++o) out[o] = load_bias_tile(b1 + 32 * o, h);
-#pragma unroll
-  for (int t = 0; t < HT; ++t) {
-    f32x16 hid = load_bias_tile(b0 + 32 * t, h);
-    const int s0 = t * kPer;
-#pragma unroll
-    for (int u = 0; u < 2 * IT; ++u) ring.step(s0 + u, xi[u >> 1][u & 1], hid, nxt(s0 + u));
+  layer_pair<P, IT, OT, HT>(ring, 0, nxt, xi, hid0, b0, h, out, [&](int t, f32x16& hid) {
     relu16(hid);
     if (G.hid_out != nullptr && rb.live) store_tile(G.hid_out + (size_t)rb.row * (32 * HT) + 32 * t + 4 * h, hid);
-    Parts<P> xh[2];
-    make_parts<P>(hid, 0, xh[0]);
-    make_parts<P>(hid, 1, xh[1]);
-#pragma unroll
-    for (int u = 0; u < 2 * OT; ++u) ring.step(s0 + 2 * IT + u, xh[u & 1], out[u >> 1], nxt(s0 + 2 * IT + u));
-  }
+  });
+  GN_STAMP(unit, 2);
   if (rb.live) {
 #pragma unroll
     for (int o = 0; o < OT; ++o) store_out_tile(reinterpret_cast<T*>(G.y), rb.row, ldy, dout, o, h, out[o]);
   }
+  GN_STAMP(unit, 4);
+  GN_STAMP(unit, 9);
 }
 
 }  // namespace

@@ -249,14 +249,32 @@ __device__ __forceinline__ void mlp2_rows(const gn_mlp2_group_t& G, int row, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const T* fb = reinterpret_cast<const T*>(G.feat) + (size_t)b * E * GN_FEAT;
-    if (G.H != nullptr) {
+    if (G.H != nullptr && E <= 16) {
+      // few hyperedges: read every feat row of the scene (they sit in L1/L2: the scene's lanes share them) weighted by
+      // H, four rows in flight — a branch per edge would serialise one memory latency per member
+      const float* hcol = G.H + (size_t)b * E * N + n;
+      int e = 0;
+      for (; e + 4 <= E; e += 4) {
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = hcol[(size_t)(e + u) * N];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add_row(fb + (size_t)(e + u) * GN_FEAT, w[u], h, acc);
+      }
+      for (; e < E; ++e) add_row(fb + (size_t)e * GN_FEAT, hcol[(size_t)e * N], h, acc);
+    } else if (G.H != nullptr) {
       const float* hcol = G.H + (size_t)b * E * N + n;
       for (int e = 0; e < E; ++e) {
         const float hv = hcol[(size_t)e * N];
         if (hv != 0.f) add_row(fb + (size_t)e * GN_FEAT, hv, h, acc);
       }
     } else if (G.sym) {
-      for (int j = 0; j < N; ++j) add_row(fb + (size_t)gn_pair_index(n, j, N) * GN_FEAT, 1.f, h, acc);
+      int j = 0;
+      for (; j + 4 <= N; j += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add_row(fb + (size_t)gn_pair_index(n, j + u, N) * GN_FEAT, 1.f, h, acc);
+      }
+      for (; j < N; ++j) add_row(fb + (size_t)gn_pair_index(n, j, N) * GN_FEAT, 1.f, h, acc);
     } else {
       for (int j = 0; j < N; ++j) {
         add_row(fb + (size_t)(n * N + j) * GN_FEAT, 1.f, h, acc);
@@ -305,8 +323,11 @@ struct AggGroup {
   int stage;   // pair form, wpr == 1: the workgroup stages the per-node pre-activations of its scenes in LDS
 };
 constexpr int kStagePitch = 128 + 4;                 // floats per staged node row (one type)
-constexpr int kStageFloats = 4 * 32 * 64;            // the LDS the kernel owns (shared with the wpr > 1 partial sums)
+constexpr int kStageFloats = 4 * 32 * 64;            // the LDS agg_mlp_kernel owns (shared with the wpr > 1 partial sums)
 constexpr int kStageMaxNodes = kStageFloats / kStagePitch;
+constexpr int kStageBuf = 4 * 32 * (64 + 8) / 2;     // agg_x_kernel: floats per buffer of its double-buffered stage
+constexpr int kStageMaxNodesX = kStageBuf / kStagePitch;
+constexpr int kStageLoadsX = (kStageMaxNodesX * 32 + 255) / 256;
 constexpr int kStageLoads = (kStageMaxNodes * 32 + 255) / 256;
 
 inline int row_grid(int rows) { return (rows + 127) / 128; }  // 4 waves x 32 rows per block

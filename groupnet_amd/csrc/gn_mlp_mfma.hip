@@ -991,7 +991,8 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
     T.g[g].wpr = wpr;
     // pair form with one wave per row block: stage the scenes' node rows in LDS when they fit
     static const bool no_stage = getenv("GN_AGG_NO_STAGE") != nullptr;
-    T.g[g].stage = (!no_stage && G.A != nullptr && wpr == 1 && (127 / G.E + 2) * G.N <= kStageMaxNodes) ? 1 : 0;
+    T.g[g].stage = (!no_stage && G.A != nullptr && wpr == 1 &&
+                    (127 / G.E + 2) * G.N <= (xm ? kStageMaxNodesX : kStageMaxNodes)) ? 1 : 0;
   }
   // Workgroups are dispatched in index order: give the low indices to the group whose waves run longest
   // (types x layers per wave), so the long waves start first and the short ones fill the tail.

@@ -30,7 +30,7 @@ class GraphedMultiScale:
     """
 
     def __init__(self, block: MultiScaleHGNN, B: int, N: int, seed: int = 0, device: Optional[torch.device] = None,
-                 warmup: int = 2):
+                 warmup: int = 2, dtype: torch.dtype = torch.float32):
         p = next(block.parameters())
         self.device = device or p.device
         if self.device.type != "cuda":
@@ -38,7 +38,7 @@ class GraphedMultiScale:
         self.block = block
         self.B, self.N = B, N
         self.seed = int(seed)
-        self.f_in = torch.zeros((B, N, block.h_dim), dtype=torch.float32, device=self.device)
+        self.f_in = torch.zeros((B, N, block.h_dim), dtype=dtype, device=self.device)    # bf16: the twins (config 4)
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.draws_per_step = sum(b * e * k for (b, e, k) in block.noise_shapes(B, N)) * block.interaction.nmp_layers
         self.graph = torch.cuda.CUDAGraph()

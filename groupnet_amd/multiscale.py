@@ -40,7 +40,14 @@ def multiscale_autograd(pair: MS_HGNN_oridinary, hypers: Sequence[MS_HGNN_hyper]
     else:
         Hs, new_H = [], None
     mods = (pair, *hypers)
-    nz = tuple(noise_u) if noise_u is not None else (None,) * (1 + S)
+    if noise_u is None:
+        # draw as the no-grad path (and the reference) does: module-major — every round of the pairwise module,
+        # then scale by scale — so that a seeded training forward sees the noise of the seeded inference forward
+        from .MS_HGNN_batch import _draw_uniform
+        B, N = fd.shape[0], fd.shape[1]
+        shapes = [(B, N * N, pair.edge_types)] + [(B, H.shape[1], m.edge_types) for H, m in zip(Hs, hypers)]
+        noise_u = [[_draw_uniform(shp, fd.device) for _ in range(pair.nmp_layers)] for shp in shapes]
+    nz = tuple(noise_u)
     if len(nz) != 1 + S:
         raise ValueError(f"noise_u: need {1 + S} entries (pairwise + one per scale)")
     params = [p for m in mods for p in _plist(m)]

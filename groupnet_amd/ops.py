@@ -387,6 +387,18 @@ class PackPlan:
                   "gn_pack_segments_f32")
 
 
+def pipeline_order(HT: int) -> List[Tuple[str, int]]:
+    """Order in which the bf16-core kernels consume the tiles of one layer pair with HT hidden tiles
+    (gn_mlp_bf16.hpp, layer_pair): A_t = the first-layer tiles producing hidden tile t, B_t = the second-layer
+    tiles consuming it;  A0 A1 B0 A2 B1 ... A(HT-1) B(HT-2) B(HT-1)."""
+    out = [("A", 0)]
+    for t in range(HT):
+        if t + 1 < HT:
+            out.append(("A", t + 1))
+        out.append(("B", t))
+    return out
+
+
 def _groups(n: int) -> None:
     if not 1 <= n <= _lib.MAX_GROUPS:
         raise ValueError(f"1..{_lib.MAX_GROUPS} groups per launch, got {n}")

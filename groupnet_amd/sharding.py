@@ -85,6 +85,33 @@ def all_gather_rows(local: Tensor, B: int, group=None) -> Tensor:
     return out
 
 
+def default_shard_noise(block, B: int, N: int, start: int, stop: int, device) -> List:
+    """The noise a rank owning scenes [start, stop) of a B-scene batch must use so that the sharded run equals
+    the single-device run with default noise: its rows of the FULL-batch streams.  `block` provides
+    ``noise_shapes(B, N)`` (one (B,E,K) per module) and ``interaction.nmp_layers``.
+      host mode   — every rank draws the full-batch uniforms exactly as one device would (same global CPU
+                    generator state on every rank, module-major: all rounds of the pairwise module, then scale by
+                    scale) and keeps its rows;
+      device mode — per module and round a `PhiloxNoise` positioned at the rank's first row inside the module's
+                    span of the stream (spans laid out back to back in the same module-major order)."""
+    from . import MS_HGNN_batch as M
+    from .ops import PhiloxNoise
+    shapes = block.noise_shapes(B, N)
+    nmp = block.interaction.nmp_layers
+    if M._NoiseState.mode == "host":
+        full = [[torch.rand(shp).float() for _ in range(nmp)] for shp in shapes]
+        return [[u[start:stop].contiguous().to(device, non_blocking=True) for u in per] for per in full]
+    out, cur = [], M._NoiseState.offset
+    for (b, e, k) in shapes:
+        per = []
+        for _ in range(nmp):
+            per.append(PhiloxNoise(M._NoiseState.seed, cur + start * e * k, M._NoiseState.counter))
+            cur += b * e * k
+        out.append(per)
+    M._NoiseState.offset = cur
+    return out
+
+
 def sharded_forward(block: Callable[..., Tuple[Tensor, Optional[Tensor]]], f_full: Tensor,
                     noise_full: Optional[Sequence] = None, group=None, gather_H: bool = False):
     """Run `block` on this rank's scenes of `f_full` (every rank holds the full input, as a
@@ -92,6 +119,9 @@ def sharded_forward(block: Callable[..., Tuple[Tensor, Optional[Tensor]]], f_ful
 
     `block(f_local, noise_u=...)` -> `(features (b, N, F), H (b, E, N) or None)`;
     ``groupnet_amd.multiscale.MultiScaleHGNN`` has this signature.
+    ``noise_full`` = the full-batch uniforms (sliced here), or None: every rank then takes its rows of the
+    full-batch default streams (`default_shard_noise`), so that the result equals a single-device run —
+    never the same noise on different scene shards.
     Returns `(features_full (B, N, F), H_full or local H)`.
     """
     world = dist.get_world_size(group)
@@ -99,7 +129,12 @@ def sharded_forward(block: Callable[..., Tuple[Tensor, Optional[Tensor]]], f_ful
     B = f_full.shape[0]
     s, e = shard_range(B, rank, world)
     f_local = f_full[s:e].contiguous()
-    noise_local = None if noise_full is None else slice_noise(noise_full, s, e)
+    if noise_full is not None:
+        noise_local = slice_noise(noise_full, s, e)
+    elif hasattr(block, "noise_shapes"):
+        noise_local = default_shard_noise(block, B, f_full.shape[1], s, e, f_full.device)
+    else:
+        noise_local = None
     feats, H = block(f_local, noise_u=noise_local)
     feats_full = all_gather_rows(feats, B, group)
     if gather_H and H is not None:
@@ -142,3 +177,94 @@ def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None, averag
             else:
                 p.grad.copy_(g)
             off += n
+
+
+class BucketedGather:
+    """The one exchange of a batch-sharded forward — the all-gather of the output embeddings — bucketed.
+
+    xGMI is point-to-point (7 links per GPU), so an all-gather is per-link bound and small messages are dominated
+    by launch latency: `slots` consecutive steps (e.g. one per compute stream of a throughput caller) fill one
+    BANK of a double-buffered staging area and are gathered by ONE `all_gather_into_tensor` call — `slots` x
+    larger messages — issued on a side stream so that it overlaps the next bank's compute.
+
+        bg = BucketedGather(slots=4, local_shape=(512, 11, 320), device=dev)
+        for k in range(steps):
+            out = run_step(k)                       # on whatever stream the caller likes
+            bg.put(out)                             # copies into the bank; gathers when the bank is full
+        bg.flush()                                  # a partial last bank is gathered too
+        bg.wait()                                   # host-side join of the gather stream
+        bg.gathered(bank)                           # (world * slots, *local_shape): rank-major, slot-minor
+
+    Bank reuse is ordered by events: a step that writes slot i of a bank first waits for the gather that last read
+    that bank.  Works on CPU tensors with the gloo backend too (no streams there: everything is synchronous),
+    which is how the logic is tested without GPUs."""
+
+    def __init__(self, slots: int, local_shape: Sequence[int], device, dtype=torch.float32, group=None):
+        if slots < 1:
+            raise ValueError("slots >= 1")
+        self.slots, self.group = int(slots), group
+        self.world = dist.get_world_size(group)
+        self.local_shape = tuple(int(d) for d in local_shape)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.banks = torch.empty((2, self.slots) + self.local_shape, dtype=dtype, device=self.device)
+        self.out = torch.empty((2, self.world * self.slots) + self.local_shape, dtype=dtype, device=self.device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.bank_free = [None, None]        # event: the gather that last read this bank has finished
+        self.ready = [None] * self.slots     # event: slot i of the current bank has been written
+        self.k = 0                           # steps put so far
+        self.count = [0, 0]                  # valid slots in the last gather of each bank
+        self.gathers = 0
+
+    def put(self, out: Tensor) -> int:
+        """Stage one step's local output (on the caller's current stream); returns the bank it went to."""
+        if tuple(out.shape) != self.local_shape:
+            raise ValueError(f"expected {self.local_shape}, got {tuple(out.shape)}")
+        i, bank = self.k % self.slots, (self.k // self.slots) % 2
+        self.k += 1
+        if self.cuda:
+            cur = torch.cuda.current_stream(self.device)
+            if self.bank_free[bank] is not None:
+                cur.wait_event(self.bank_free[bank])
+            self.banks[bank, i].copy_(out, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self.ready[i] = ev
+        else:
+            self.banks[bank, i].copy_(out)
+        if i == self.slots - 1:
+            self._gather(bank, self.slots)
+        return bank
+
+    def _gather(self, bank: int, count: int) -> None:
+        src = self.banks[bank].view((self.slots * self.local_shape[0],) + self.local_shape[1:])
+        dst = self.out[bank].view((self.world * self.slots * self.local_shape[0],) + self.local_shape[1:])
+        if self.cuda:
+            with torch.cuda.stream(self.stream):
+                for ev in self.ready[:count]:
+                    if ev is not None:
+                        self.stream.wait_event(ev)
+                dist.all_gather_into_tensor(dst, src, group=self.group)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                self.bank_free[bank] = ev
+        else:
+            dist.all_gather_into_tensor(dst, src, group=self.group)
+        self.count[bank] = count
+        self.gathers += 1
+
+    def flush(self) -> None:
+        """Gather a partially filled bank (step count not a multiple of `slots`); the unfilled slots carry stale
+        bytes — `count[bank]` says how many are valid.  Every rank must call it at the same step."""
+        rem = self.k % self.slots
+        if rem:
+            self._gather((self.k // self.slots) % 2, rem)
+            self.k += self.slots - rem          # the next put starts a fresh bank
+
+    def wait(self) -> None:
+        if self.cuda:
+            self.stream.synchronize()
+
+    def gathered(self, bank: int) -> Tensor:
+        """(world, slots, *local_shape) view of the last gather of `bank`: [r, i] = rank r's step in slot i."""
+        return self.out[bank].view((self.world, self.slots) + self.local_shape)

@@ -2,8 +2,8 @@
 
 This file is a checker, not a product path: only ``tests/``,
 ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
-import it.  ``groupnet_amd`` never does (tests/test_no_oracle_in_product.py
-enforces that).
+import it.  ``groupnet_amd`` never does (tests/test_capi_cpu.py::
+test_product_never_touches_the_oracle enforces that).
 
 It restates, op for op and in plain fp32 torch on the CPU, what the reference
 does in ``model/MS_HGNN_batch.py`` and in the three affinity lines of
@@ -315,6 +315,60 @@ def ms_hgnn_multiscale_forward(state_pair: State, states_hyper: Sequence[State],
         feats.append(nf)
         Hs.append(H)
     return torch.cat(feats, dim=-1), (torch.cat(Hs, dim=1) if Hs else None), corr
+
+
+# --------------------------------------------------------------------------
+# large N: the pairwise module in slabs of edges (BASELINE config 5, N = 256: E = 65 536 edges per scene)
+# --------------------------------------------------------------------------
+def pairwise_incidence_rows(N: int, e0: int, e1: int, dtype=torch.float32) -> Tensor:
+    """Rows [e0, e1) of ``pairwise_incidence`` (MS_HGNN_batch.py:143-160,118,124) without the other N*N - (e1-e0)."""
+    e = torch.arange(e0, e1)
+    H = torch.zeros(e1 - e0, N, dtype=dtype)
+    r = torch.arange(e1 - e0)
+    H[r, e % N] += 1
+    H[r, e // N] += 1
+    return H
+
+
+def ms_hgnn_pairwise_forward_chunked(state: State, h: Tensor, U_list: List[Tensor], slab: int = 4096
+                                     ) -> Tuple[Tensor, Tensor]:
+    """``MS_HGNN_oridinary.forward`` with nmp_layers = 1 (MS_HGNN_batch.py:162-198) evaluated in slabs of `slab`
+    edges, for N where neither the (B,E,N,128) attention input of the reference (:129-132) nor the (B,E,N,32)
+    hidden tensor of the decomposed form fits in memory.  Edges are independent in ``node2edge`` (:122-141) and in
+    the typed MLP of ``edge2node`` (:116-120, 259-268); the only coupling is the sum over edges
+    ``H^T @ feat`` (:267), which is accumulated slab by slab (in float64, rounded once — the reference's single fp32
+    matmul sums the same terms).  Same operations per edge as `node2edge(decomposed=True)` / `edge_mlp_gumbel` /
+    `aggregate_typed_mlp`; `tests/test_oracle_golden.py` checks it against the unchunked oracle (itself pinned by
+    the reference's goldens) at every golden N, with slabs that do not divide E."""
+    B, N, D = h.shape
+    E = N * N
+    U = U_list[0]
+    xp = mlp(state, "node2edge_start_mlp.0", h)                              # :125
+    W1 = state["attention_mlp.0.layers.0.weight"]
+    b1 = state["attention_mlp.0.layers.0.bias"]
+    W2 = state["attention_mlp.0.layers.1.weight"]
+    b2 = state["attention_mlp.0.layers.1.bias"]
+    P = F.linear(xp, W1[:, :D], b1)                                          # node half of attention layer 0
+    node = torch.zeros(B, N, D, dtype=torch.float64)
+    factors = torch.empty(B, E, EDGE_TYPES_PAIRWISE, dtype=h.dtype)
+    for e0 in range(0, E, slab):
+        e1 = min(E, e0 + slab)
+        Hs = pairwise_incidence_rows(N, e0, e1, h.dtype)[None]               # (1, slab, N)
+        edge_init = torch.matmul(Hs, xp)                                      # :127
+        Q = F.linear(edge_init, W1[:, D:])
+        hid = torch.relu(P[:, None, :, :] + Q[:, :, None, :])                # (B, slab, N, 32)
+        att = torch.matmul(hid, W2[0]) + b2[0]                                # :131-134
+        del hid
+        Hw = torch.softmax(att * Hs, dim=2) * Hs                              # :135-137
+        edges = torch.matmul(Hw, xp)                                          # :138
+        edge_feat, dist = edge_mlp_gumbel(state, "nmp_mlp_start", edges, U[:, e0:e1])    # :177
+        factors[:, e0:e1] = dist
+        eo = torch.matmul(Hs, h)                                              # edge_aggregation :263
+        feat = aggregate_typed_mlp(state, "edge_aggregation_list.0", edge_feat, eo)
+        node += torch.matmul(Hs.permute(0, 2, 1).double(), feat.double())     # :267, summed over slabs
+    agg = torch.cat((node.to(h.dtype), h), dim=-1)
+    agg = agg / agg.size(1)                                                   # :120
+    return mlp(state, "nmp_mlp_end", agg), factors
 
 
 # --------------------------------------------------------------------------

@@ -1,0 +1,234 @@
+"""GPU parity tests of the bf16 twins (BASELINE config 4: N=50, B=1024, scales {2,4,8,16}, bf16
+storage / fp32 accumulate), all through the C ABI (`gn_*_bf16`).
+
+What "parity" means for a reduced-precision storage type.  The reference is an fp32 program; its bf16 twin
+rounds every tensor that goes through HBM — inputs, weights, and every inter-layer activation — to bf16 (8
+significant bits, unit round-off u = 2^-9 ~ 0.002) and accumulates in fp32.  A feature is reached through ~10
+roundings (node MLP, pooling, edge MLP, typed aggregation, closing MLP, two matrix layers each), every one
+followed by a fan-in of 64..256 terms whose rounding errors add incoherently, so the expected deviation from the
+fp32 result is a few u of the feature scale and 1e-5 is unreachable by construction.  The gates used here, with
+the measured values printed by every test:
+  * incidence H: BIT-EXACT against the oracle fed the same bf16-rounded agent features (affinity and ranking
+    run in fp32 on those values; rows whose k-th / (k+1)-th affinity gap is below 1e-5 are excluded, as in the
+    fp32 tests, because torch.topk's tie order is unspecified — their share is asserted to be < 0.5 %);
+  * features and edge-type distributions: |twin - fp32 oracle| <= 1.5e-2 * max|oracle| (measured 3e-3 .. 4.5e-3),
+    and <= 1.5e-2 of the same scale against the library's own fp32 path on identical (bf16-representable) inputs;
+  * byte-moving stages (gather, scatter): the twin equals the fp32 kernel's result rounded once to bf16, bit for
+    bit — same summation order, one final rounding.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ms_hgnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_ORACLE = 1.5e-2   # of max|oracle feature| (measured 3e-3 .. 4.5e-3), see module docstring
+TOL_FP32PATH = 1.5e-2
+GAP = 1e-5            # minimum k-th / (k+1)-th affinity gap for a row's H to be compared bit for bit
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def relerr(a, ref):
+    a, ref = a.detach().float().cpu(), ref.detach().float().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    return float((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def block_and_states(scales, seed):
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    torch.manual_seed(seed)
+    blk = MultiScaleHGNN(scales)
+    sp = {k: v.detach().clone() for k, v in blk.interaction.state_dict().items()}
+    shs = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in blk.interaction_hyper]
+    return blk.to(dev()).eval(), sp, shs
+
+
+def safe_rows(corr, scale):
+    """Rows of corr whose top-`scale` set is separated from the rest by more than GAP (B,N) bool."""
+    N = corr.shape[-1]
+    if scale >= N:
+        return torch.ones(corr.shape[:2], dtype=torch.bool)
+    v = torch.sort(corr, dim=-1, descending=True).values
+    return (v[..., scale - 1] - v[..., scale]) > GAP
+
+
+@pytest.mark.parametrize("B,N,scales", [(6, 11, [2, 5, 11]), (2, 50, [2, 4, 8, 16])])
+def test_bf16_block_matches_fp32_oracle(B, N, scales):
+    """The whole multiscale block on bf16 storage vs the fp32 oracle (decomposed attention) on the same
+    bf16-rounded agent features and the same uniforms.  N=50 / scales {2,4,8,16} is BASELINE config 4's shape."""
+    blk, sp, shs = block_and_states(scales, seed=11)
+    h = torch.randn(B, N, 64).bfloat16()
+    noise = [[torch.rand(s)] for s in blk.noise_shapes(B, N)]
+    with torch.no_grad():
+        ref, Href, corr = O.ms_hgnn_multiscale_forward(sp, shs, scales, h.float(), noise[0], noise[1:], decomposed=True)
+        out, H = blk(h.to(dev()), noise_u=[[u.to(dev()) for u in n] for n in noise])
+    assert out.dtype == torch.bfloat16 and H.dtype == torch.bfloat16
+    assert out.shape == (B, N, 64 * (2 + len(scales)))
+    assert torch.equal(out[..., :64].cpu(), h)                       # f is copied through unchanged
+    # incidence: exact on every row that is not a near-tie
+    Hc, row0, unsafe, total = H.float().cpu(), 0, 0, 0
+    for s in scales:
+        E = 1 if s == N else N
+        got, want = Hc[:, row0:row0 + E], Href[:, row0:row0 + E]
+        if s != N:
+            ok = safe_rows(corr, s)
+            unsafe += int((~ok).sum())
+            total += ok.numel()
+            assert torch.equal(got[ok], want[ok]), f"scale {s}: incidence differs on tie-free rows"
+            assert bool((got.sum(-1) == s).all())
+        else:
+            assert torch.equal(got, want)
+        row0 += E
+    assert unsafe <= 0.005 * max(total, 1), (unsafe, total)
+    errs = [relerr(out[..., 64 * (1 + i):64 * (2 + i)], ref[..., 64 * (1 + i):64 * (2 + i)]) for i in range(1 + len(scales))]
+    print(f"\nbf16 twin vs fp32 oracle, B={B} N={N} scales={scales}: max rel err per module "
+          f"{['%.2e' % e for e in errs]} (gate {TOL_ORACLE:g}); near-tie rows {unsafe}/{total}")
+    assert max(errs) <= TOL_ORACLE
+
+
+def test_bf16_modules_return_reference_shaped_tuples():
+    """Drop-in surface on bf16 tensors: MS_HGNN_oridinary -> (node_feat, factors), MS_HGNN_hyper ->
+    (node_feat, factor, H), every returned tensor in the input's dtype (`type_as(feat)`,
+    model/MS_HGNN_batch.py:376,384), factors rows summing to 1."""
+    import groupnet_amd as G
+    torch.manual_seed(3)
+    pair = G.MS_HGNN_oridinary(embedding_dim=16, h_dim=64, mlp_dim=64, bottleneck_dim=64, batch_norm=0, nmp_layers=1)
+    hyper = G.MS_HGNN_hyper(embedding_dim=64, h_dim=64, mlp_dim=64, bottleneck_dim=64, batch_norm=0, nmp_layers=2,
+                            scale=4)
+    sp = {k: v.detach().clone() for k, v in pair.state_dict().items()}
+    sh = {k: v.detach().clone() for k, v in hyper.state_dict().items()}
+    pair.to(dev()).eval(), hyper.to(dev()).eval()
+    B, N = 5, 13
+    h = torch.randn(B, N, 64).bfloat16()
+    corr = O.affinity(h.float())
+    Up, Uh = [torch.rand(B, N * N, 6)], [torch.rand(B, N, 10) for _ in range(2)]
+    with torch.no_grad():
+        nf, fac = pair(h.to(dev()), noise_u=[u.to(dev()) for u in Up])
+        nh, fh, H = hyper(h.to(dev()), corr.to(dev()), noise_u=[u.to(dev()) for u in Uh])
+        rp, rfac = O.ms_hgnn_pairwise_forward(sp, h.float(), Up, decomposed=True)
+        rh, rfh, rH = O.ms_hgnn_hyper_forward(sh, h.float(), corr, 4, Uh, nmp_layers=2, decomposed=True)
+    for t in (nf, fac, nh, fh, H):
+        assert t.dtype == torch.bfloat16
+    assert nf.shape == (B, N, 64) and fac.shape == (B, N * N, 6) and fh.shape == (B, N, 10) and H.shape == (B, N, N)
+    assert torch.equal(H.float().cpu(), rH)
+    errs = dict(pair=relerr(nf, rp), pair_factors=relerr(fac, rfac), hyper=relerr(nh, rh), hyper_factor=relerr(fh, rfh))
+    print("\nbf16 modules vs fp32 oracle:", {k: "%.2e" % v for k, v in errs.items()})
+    assert max(errs.values()) <= TOL_ORACLE
+    assert float((fac.float().sum(-1) - 1).abs().max()) <= 2e-2       # K bf16 roundings of a distribution
+
+
+def test_bf16_twin_vs_fp32_path_same_inputs():
+    """The twin against the library's own fp32 path on identical bf16-representable inputs and identical
+    uniforms: same incidence, features within 2e-2 of the feature scale."""
+    blk, _, _ = block_and_states([2, 5, 11], seed=5)
+    B, N = 64, 11
+    h = torch.randn(B, N, 64, device=dev()).bfloat16()
+    noise = [[torch.rand(s).to(dev())] for s in blk.noise_shapes(B, N)]
+    with torch.no_grad():
+        o32, H32 = blk(h.float(), noise_u=noise)
+        o16, H16 = blk(h, noise_u=noise)
+    assert torch.equal(H16.float(), H32)
+    e = relerr(o16[..., 64:], o32[..., 64:])
+    print(f"\nbf16 twin vs fp32 path: max rel err {e:.2e} (gate {TOL_FP32PATH:g})")
+    assert e <= TOL_FP32PATH
+
+
+def test_bf16_gather_scatter_equal_fp32_kernels_rounded_once():
+    from groupnet_amd import ops
+    torch.manual_seed(2)
+    B, N = 33, 19
+    ori = torch.randn(B, N, 64, device=dev()).bfloat16()
+    feat = torch.randn(B, N, 64, device=dev()).bfloat16()
+    _, Hs, _ = ops.affinity_topk(ori, [5], want_corr=False)
+    H = Hs[0]
+    assert H.dtype == torch.float32
+    eo16, eo32 = ops.agg_gather(ori, H), ops.agg_gather(ori.float(), H)
+    assert eo16.dtype == torch.bfloat16 and torch.equal(eo16, eo32.bfloat16())
+    s16, s32 = ops.agg_scatter(feat, H, ori), ops.agg_scatter(feat.float(), H, ori.float())
+    assert torch.equal(s16, s32.bfloat16())
+    # implicit pairwise graph, ordered and symmetric forms
+    for sym in (False, True):
+        E = ops.pair_count(N) if sym else N * N
+        fe = torch.randn(B, E, 64, device=dev()).bfloat16()
+        assert torch.equal(ops.agg_gather(ori, None, sym), ops.agg_gather(ori.float(), None, sym).bfloat16())
+        assert torch.equal(ops.agg_scatter(fe, None, ori, sym=sym), ops.agg_scatter(fe.float(), None, ori.float(), sym=sym).bfloat16())
+
+
+def test_bf16_fused_affinity_topk_ranks_in_fp32():
+    """gn_affinity_topk_bf16: H of every scale equals the fp32 kernel's on the same (bf16-representable) f; the
+    concatenation is written in bf16, f is copied through."""
+    from groupnet_amd import ops
+    torch.manual_seed(9)
+    B, N = 40, 50
+    f = torch.randn(B, N, 64, device=dev()).bfloat16()
+    final = torch.empty(B, N, 128, device=dev(), dtype=torch.bfloat16)
+    corr16, Hs16, Hcat16 = ops.affinity_topk(f, [2, 4, 8, 16], want_corr=True, f_out=final[..., :64], want_H_cat=True)
+    corr32, Hs32, Hcat32 = ops.affinity_topk(f.float(), [2, 4, 8, 16], want_corr=True, want_H_cat=True)
+    assert corr16.dtype == torch.float32 and torch.equal(corr16, corr32)
+    for a, b in zip(Hs16, Hs32):
+        assert a.dtype == torch.float32 and torch.equal(a, b)
+    assert Hcat16.dtype == torch.bfloat16 and torch.equal(Hcat16.float(), Hcat32)
+    assert torch.equal(final[..., :64], f)
+
+
+def test_bf16_twins_are_forward_only():
+    blk, _, _ = block_and_states([2, 11], seed=1)
+    h = torch.randn(4, 11, 64, device=dev()).bfloat16()
+    with pytest.raises(NotImplementedError):
+        blk(h)                                   # parameters require grad and autograd is recording
+    with torch.no_grad():
+        out, _ = blk(h)
+    assert out.dtype == torch.bfloat16
+
+
+def test_config4_full_size_properties_bf16():
+    """BASELINE config 4 at full size: B=1024, N=50, scales {2,4,8,16}, bf16, device noise.  Size-independent
+    properties: incidence row sums, f copied through, finite outputs, distributions summing to 1, bit-exact
+    scene-permutation equivariance, batch-shard invariance (shards may pick different work shapes: tolerance)."""
+    import groupnet_amd as G
+    blk, _, _ = block_and_states([2, 4, 8, 16], seed=7)
+    B, N = 1024, 50
+    torch.manual_seed(123)
+    h = torch.randn(B, N, 64, device=dev()).bfloat16()
+    noise = lambda: [[G.ops.PhiloxNoise(77, off)] for off in _offsets(blk, B, N)]
+    with torch.no_grad():
+        out, H = blk(h, noise_u=noise())
+        assert out.shape == (B, N, 64 * 6) and H.shape == (B, 4 * N, N) and out.dtype == torch.bfloat16
+        assert bool(torch.isfinite(out.float()).all())
+        assert torch.equal(out[..., :64], h)
+        for i, s in enumerate([2, 4, 8, 16]):
+            assert bool((H[:, i * N:(i + 1) * N].float().sum(-1) == s).all())
+        # the pairwise module's factors at full size: rows are distributions
+        _, fac = blk.interaction(h[:256].contiguous(), noise_u=[G.ops.PhiloxNoise(5, 0)])
+        assert fac.shape == (256, N * N, 6) and float((fac.float().sum(-1) - 1).abs().max()) <= 2e-2
+        # batch-shard invariance: the second half alone, with its rows of the full-batch noise stream
+        half = B // 2
+        o2, H2 = blk(h[half:].contiguous(), noise_u=[[G.ops.PhiloxNoise(77, off + half * e * k)]
+                                                      for off, (_, e, k) in zip(_offsets(blk, B, N), blk.noise_shapes(B, N))])
+        assert torch.equal(H2, H[half:])
+        e = relerr(o2[..., 64:], out[half:, :, 64:])
+        print(f"\nconfig 4 bf16: shard-vs-full max rel diff {e:.2e}")
+        assert e <= 2e-2
+    # scene-permutation equivariance with injected (permuted) uniform tensors, bit for bit — on a slice of the
+    # batch (host uniforms for 1024 scenes x 2500 edges would be 61 MB per draw: fine, but keep the test light)
+    Bs = 64
+    hs = h[:Bs].contiguous()
+    U = [[torch.rand(s, device=dev())] for s in blk.noise_shapes(Bs, N)]
+    perm = torch.randperm(Bs, device=dev())
+    with torch.no_grad():
+        oa, Ha = blk(hs, noise_u=U)
+        ob, Hb = blk(hs[perm].contiguous(), noise_u=[[u[0][perm].contiguous()] for u in U])
+    assert torch.equal(ob, oa[perm]) and torch.equal(Hb, Ha[perm])
+
+
+def _offsets(blk, B, N):
+    offs, cur = [], 0
+    for (b, e, k) in blk.noise_shapes(B, N):
+        offs.append(cur)
+        cur += b * e * k
+    return offs

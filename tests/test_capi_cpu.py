@@ -147,3 +147,26 @@ def test_mlp_standalone_has_no_cpu_path_either():
     assert [tuple(l.weight.shape) for l in m.layers] == [(16, 8), (5, 16), (3, 5)]
     with pytest.raises(ValueError):
         m(torch.randn(4, 8))
+
+
+def test_packed_weight_cache_policy():
+    """The cache fingerprint (address, in-place version) misses `.data` writes — so while autograd records for the
+    parameters the cache must not be trusted (`_volatile`), and only then."""
+    from groupnet_amd import MS_HGNN_batch as M
+    lin = torch.nn.Linear(4, 3)
+    params = list(lin.parameters())
+    k0 = M._param_key(params)
+    lin.weight.data.mul_(2.0)
+    assert M._param_key(params) == k0                    # the blind spot
+    with torch.no_grad():
+        lin.weight.mul_(2.0)
+    assert M._param_key(params) != k0                    # ordinary in-place updates are seen
+    assert M._volatile(params)                           # grad mode on, parameters trainable: re-pack every call
+    with torch.no_grad():
+        assert not M._volatile(params)                   # inference: cache trusted
+        with M.training_call():
+            assert M._volatile(params)                   # the forward of an autograd Function runs under no_grad
+        assert not M._volatile(params)
+    for p in params:
+        p.requires_grad_(False)
+    assert not M._volatile(params)                       # frozen parameters

@@ -211,3 +211,20 @@ def test_oracle_autograd_matches_reference_gradients(name):
             if f"{prefix}_g/{n}" in c:
                 full = torch.from_numpy(c[f"{prefix}_g/{n}"])
                 assert float((g - full).abs().max()) <= 1e-5 * float(full.abs().max()) + 1e-8, n
+
+
+@pytest.mark.parametrize("name,slab", [("syn_n11_b37", 50), ("syn_n5_b4", 7), ("syn_n50_b3", 999), ("nba_b10", 121)])
+def test_chunked_pairwise_oracle_equals_the_pinned_oracle(name, slab):
+    """The slab-wise pairwise oracle used at N = 256 (config 5) against the reference's golden outputs and the
+    unchunked oracle, with slabs that do not divide E."""
+    c = load_case(name)
+    sp, _, nmp = weights_for(name)
+    assert nmp == 1
+    h = torch.from_numpy(c["h"])
+    U = uniforms(c, "pair")
+    with torch.no_grad():
+        nf, fac = O.ms_hgnn_pairwise_forward_chunked(sp, h, U, slab=slab)
+        nf0, fac0 = O.ms_hgnn_pairwise_forward(sp, h, U, decomposed=True)
+    assert float((nf - nf0).abs().max()) <= 1e-6 and float((fac - fac0).abs().max()) <= 1e-6
+    assert float((nf - torch.from_numpy(c["pair_node_feat"])).abs().max()) <= 1e-6
+    assert float((fac - torch.from_numpy(c["pair_factors"])).abs().max()) <= 1e-6

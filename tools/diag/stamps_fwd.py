@@ -1,0 +1,64 @@
+"""Diagnostic (not product): per-wave cycle stamps of the bf16-core kernels of one forward, -DGN_STAMPS build.
+Each stage is run alone (the stamp buffer is shared) after a full forward produced its inputs."""
+import os, sys, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ["GROUPNET_HIP_LIB"] = os.path.join(ROOT, "tools", "diag", sys.argv[1])
+import numpy as np
+import torch
+from groupnet_amd import _lib, ops
+from groupnet_amd.multiscale import MultiScaleHGNN
+import groupnet_amd as G
+import groupnet_amd.MS_HGNN_batch as M
+
+B, N = 512, 11
+dev = torch.device("cuda")
+torch.manual_seed(0)
+blk = MultiScaleHGNN([2, 5, 11]).to(dev).eval()
+f = torch.randn(B, N, 64, device=dev)
+lib = _lib.load()
+lib.gn_debug_read_stamps.restype = ctypes.c_int
+lib.gn_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+
+def report(tag, n_units, groups=None):
+    torch.cuda.synchronize()
+    buf = np.zeros((n_units, 16), dtype=np.uint64)
+    lib.gn_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes)
+    s = buf.astype(np.int64)
+    live = s[:, 9] > 0
+    rt0 = s[live, 8].min()
+    print(f"== {tag}: {live.sum()} waves, span {(s[live, 9].max() - rt0) / 100.0:.2f} us")
+    for name, sl in (groups or [("all", slice(0, n_units))]):
+        u = s[sl][live[sl]]
+        if len(u) == 0:
+            continue
+        start, end = (u[:, 8] - rt0) / 100.0, (u[:, 9] - rt0) / 100.0
+        pro = u[:, 1] - u[:, 0]
+        body = u[:, 2] - u[:, 1]
+        tail = u[:, 4] - u[:, 2]
+        print(f"  {name:10s} n={len(u):5d} start med/max {np.median(start):5.2f}/{start.max():5.2f}  end med/max {np.median(end):5.2f}/{end.max():5.2f} us |"
+              f" cycles: prologue {np.median(pro):6.0f}  body med {np.median(body):6.0f} min {body.min():6.0f} max {body.max():6.0f}  tail {np.median(tail):6.0f}")
+
+calls = []
+orig = {}
+def wrap(name, n_units_fn, groups_fn=None):
+    fn = getattr(ops, name)
+    orig[name] = fn
+    def w(*a, **k):
+        for _ in range(5):
+            r = fn(*a, **k)
+        report(name, n_units_fn(*a, **k), groups_fn(*a, **k) if groups_fn else None)
+        return r
+    setattr(ops, name, w)
+
+wrap("node_stage_grouped", lambda items, keep, specs: 704 + 528, lambda *a: [("chain", slice(0, 704)), ("A", slice(704, 1232))])
+def edge_units(items, *a, **k):
+    return sum(((it[0].shape[0] * it[0].shape[1] + 127) // 128) * 4 for it in items)
+wrap("edge_mlp_gumbel_grouped", edge_units, lambda items, *a, **k: [("pair", slice(0, 1056)), ("hyper", slice(1056, 1056 + 400))])
+wrap("agg_mlp_grouped", lambda items: 4 * 700, None)
+wrap("mlp2_grouped", lambda items, keep=None: 4 * 44 * 4, None)
+M.ops = ops
+with torch.no_grad():
+    G.set_noise_mode("device", seed=3)
+    blk(f)
+torch.cuda.synchronize()
