@@ -34,7 +34,9 @@ from . import ops
 Tensor = torch.Tensor
 _HDIM_EXTEND = 64      # model/MS_HGNN_batch.py:72,292
 _GUMBEL_TAU = 0.5      # model/MS_HGNN_batch.py:45
-_FUSED_GATHER_MAX_N = 64   # beyond this the LDS-tiled standalone gather beats a per-lane scan of H rows
+_FUSED_GATHER_MAX_N = 16   # beyond this the stand-alone gather / scatter kernels (LDS-tiled, high occupancy) beat a per-lane
+                           # scan of H rows / a per-lane gather of N feature rows in the prologue of an MFMA kernel (latency-bound
+                           # at 1-2 waves per SIMD: 311 us vs ~100 us for the closing MLP at N = 50, B = 1024)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -608,6 +610,9 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
     def edge2node(edge_feats: Sequence[Tensor], oris: Sequence[Tensor], idx: int) -> List[Tensor]:
         aggs = [m.edge_aggregation_list[idx] for m in mods]
         items = []
+        # larger graphs: eo = H @ ori of every hyper module from ONE stand-alone gather launch
+        standalone = [i for i in range(n) if not syms[i] and N > _FUSED_GATHER_MAX_N]
+        eos = dict(zip(standalone, ops.agg_gather_grouped([(oris[i], Hs[i]) for i in standalone]))) if standalone else {}
         for i in range(n):
             pk, K = aggs[i]._packed(), aggs[i].edge_types
             if syms[i] and not twin:
@@ -620,7 +625,7 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
             elif N <= _FUSED_GATHER_MAX_N:
                 src = ops.GatherSpec(oris[i], Hs[i], False)   # eo = H @ ori formed inside the kernel
             else:
-                src = ops.agg_gather(oris[i], Hs[i])
+                src = eos[i]
             items.append((src, edge_feats[i], pk, K))
         feats = ops.agg_mlp_grouped(items)
         if N <= _FUSED_GATHER_MAX_N:

@@ -213,78 +213,97 @@ __device__ __forceinline__ int find_wave_group(const WaveTable<G>& t, long long 
 // --------------------------------------------------------------------------------------------
 // A3 second half: attention-weighted node -> edge pooling
 // --------------------------------------------------------------------------------------------
-// Hyper modules: one wave per hyperedge.  Members of the edge (nodes with H != 0) are compacted
-// into LDS; non-members enter the softmax only as exp(0 - max) terms, exactly as
-// softmax(att * H) treats them (MS_HGNN_batch.py:135-137,366-368).  `first` counts edges (waves).
+// Hyper modules.  A workgroup stages the x' and pq rows of SG scenes of ONE module in LDS (pq rows padded to 65
+// floats) and its 4 waves walk those scenes' hyperedges, one wave per hyperedge at a time: the members of the edge
+// (nodes with H != 0) are compacted with a ballot; non-members enter the softmax only as exp(0 - max) terms, exactly
+// as softmax(att * H) treats them (MS_HGNN_batch.py:135-137,366-368); every per-member access then is an LDS read
+// (the first version read the members' rows straight from L2: three dependent global loads per member and wave —
+// 305 us at N = 50, B = 1024).  `first` counts workgroups.
 template <typename TS>
-__device__ __forceinline__ void node2edge_hyper_body(const WaveTable<gn_n2e_group_t>& T, int N, int wg) {
+__device__ __forceinline__ void node2edge_hyper_body(const WaveTable<gn_n2e_group_t>& T, int B, int N, int SG, int wg) {
   extern __shared__ __align__(16) float lds[];
+  constexpr int LDP = GN_FEAT + 1;
   const int wave = gn_uniform((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-  const long long total = T.first[T.n];
-  const long long w_raw = (long long)wg * (kBlock / 64) + wave;
-  const bool live = w_raw < total;  // dead waves redo the last edge and skip the store
-  const long long w = live ? w_raw : total - 1;
-  const int gi = gn_uniform(find_wave_group(T, w));
+  const int gi = gn_uniform(find_wave_group(T, wg));
   const gn_n2e_group_t G = T.g[gi];
   const int E = G.E;
-  const long long eg = w - T.first[gi];
-  const int b = (int)(eg / E), e = (int)(eg - (long long)b * E);
-  // per-wave LDS: idx[N] (int), hval[N], att[N]
-  float* base = lds + (size_t)wave * 3 * N;
+  const int b0 = (int)(wg - T.first[gi]) * SG;
+  const int sg = min(SG, B - b0);
+  float* s_xp = lds;                                   // sg x N x 64
+  float* s_pq = s_xp + (size_t)SG * N * GN_FEAT;       // sg x N x 65
+  float* base = s_pq + (size_t)SG * N * LDP + (size_t)wave * 3 * N;   // per wave: idx[N] (int), hval[N], att[N]
   int* s_idx = reinterpret_cast<int*>(base);
   float* s_h = base + N;
   float* s_att = base + 2 * N;
-
-  int cnt = 0;
-  const float* Hrow = G.H + ((size_t)b * E + e) * N;
-  for (int n0 = 0; n0 < N; n0 += 64) {
-    const int n = n0 + lane;
-    const float hv = n < N ? Hrow[n] : 0.f;
-    const unsigned long long mask = __ballot(hv != 0.f);
-    if (hv != 0.f) {
-      const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-      s_idx[pos] = n;
-      s_h[pos] = hv;
+  {
+    const TS* src = reinterpret_cast<const TS*>(G.xp) + (size_t)b0 * N * GN_FEAT;
+    f32x4* dst = reinterpret_cast<f32x4*>(s_xp);
+    for (int idx = threadIdx.x; idx < sg * N * 16; idx += kBlock) dst[idx] = ld4(src + 4 * idx);
+    const TS* psrc = reinterpret_cast<const TS*>(G.pq) + (size_t)b0 * N * GN_FEAT;
+    for (int idx = threadIdx.x; idx < sg * N * 16; idx += kBlock) {
+      const f32x4 v = ld4(psrc + 4 * idx);
+      float* d = s_pq + (idx >> 4) * LDP + (idx & 15) * 4;
+      d[0] = v[0];
+      d[1] = v[1];
+      d[2] = v[2];
+      d[3] = v[3];
     }
-    cnt += __popcll(mask);
   }
   __syncthreads();
-
-  const TS* pqb = reinterpret_cast<const TS*>(G.pq) + (size_t)b * N * GN_FEAT;
-  const TS* xpb = reinterpret_cast<const TS*>(G.xp) + (size_t)b * N * GN_FEAT;
-  // Q_e = sum_n H[e,n] * Qn_n      (lanes 32..63 hold channel c of Qn)
-  float qe = 0.f;
-  for (int m = 0; m < cnt; ++m) qe = fmaf(s_h[m], ld1(pqb + (size_t)s_idx[m] * GN_FEAT + lane), qe);
-  const float qlo = __shfl(qe, 32 + c, GN_WAVE);  // both halves now see Q_e[c]
   const float w2c = G.w2[c];
-  // att for two members per step: half h takes member 2*t + h
-  for (int m0 = 0; m0 < cnt; m0 += 2) {
-    const int m = m0 + h;
-    const bool valid = m < cnt;
-    const int n = valid ? s_idx[m] : 0;
-    const float p = ld1(pqb + (size_t)n * GN_FEAT + c);
-    float t = valid ? w2c * fmaxf(p + qlo, 0.f) : 0.f;
-    t = gn_half_sum(t);
-    if (valid && c == 0) s_att[m] = t + *G.b2;
+  const float b2v = *G.b2;
+  for (int eidx = wave; eidx < sg * E; eidx += kBlock / 64) {
+    const int s = eidx / E, e = eidx - s * E;
+    int cnt = 0;
+    const float* Hrow = G.H + ((size_t)(b0 + s) * E + e) * N;
+    for (int n0 = 0; n0 < N; n0 += 64) {
+      const int n = n0 + lane;
+      const float hv = n < N ? Hrow[n] : 0.f;
+      const unsigned long long mask = __ballot(hv != 0.f);
+      if (hv != 0.f) {
+        const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+        s_idx[pos] = n;
+        s_h[pos] = hv;
+      }
+      cnt += __popcll(mask);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float* pqb = s_pq + (size_t)s * N * LDP;
+    const float* xpb = s_xp + (size_t)s * N * GN_FEAT;
+    // Q_e = sum_n H[e,n] * Qn_n      (lanes 32..63 hold channel c of Qn)
+    float qe = 0.f;
+    for (int m = 0; m < cnt; ++m) qe = fmaf(s_h[m], pqb[s_idx[m] * LDP + lane], qe);
+    const float qlo = __shfl(qe, 32 + c, GN_WAVE);  // both halves now see Q_e[c]
+    // att for two members per step: half h takes member 2*t + h
+    for (int m0 = 0; m0 < cnt; m0 += 2) {
+      const int m = m0 + h;
+      const bool valid = m < cnt;
+      const int n = valid ? s_idx[m] : 0;
+      const float p = pqb[n * LDP + c];
+      float t = valid ? w2c * fmaxf(p + qlo, 0.f) : 0.f;
+      t = gn_half_sum(t);
+      if (valid && c == 0) s_att[m] = t + b2v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // softmax over all N nodes of v_n = att_n * H[e,n]  (0 for non-members)
+    float mx = cnt < N ? 0.f : -INFINITY;
+    for (int m = lane; m < cnt; m += 64) mx = fmaxf(mx, s_att[m] * s_h[m]);
+    mx = gn_wave_max(mx);
+    float sum = 0.f;
+    for (int m = lane; m < cnt; m += 64) sum += expf(s_att[m] * s_h[m] - mx);
+    sum = gn_wave_sum(sum);
+    sum += gn_nonmember_sum(N - cnt, mx);
+    // edges[e] = sum_n (softmax_n * H[e,n]) * x'_n ; lane = feature
+    float acc = 0.f;
+    for (int m = 0; m < cnt; ++m) {
+      const float hv = s_h[m];
+      const float wgt = expf(s_att[m] * hv - mx) / sum * hv;
+      acc = fmaf(wgt, xpb[s_idx[m] * GN_FEAT + lane], acc);
+    }
+    st1(reinterpret_cast<TS*>(G.edges) + ((size_t)(b0 + s) * E + e) * GN_FEAT + lane, acc);
+    __builtin_amdgcn_wave_barrier();     // (the wave's scratch is rewritten by its next hyperedge)
   }
-  __syncthreads();
-  // softmax over all N nodes of v_n = att_n * H[e,n]  (0 for non-members)
-  float mx = cnt < N ? 0.f : -INFINITY;
-  for (int m = lane; m < cnt; m += 64) mx = fmaxf(mx, s_att[m] * s_h[m]);
-  mx = gn_wave_max(mx);
-  float sum = 0.f;
-  for (int m = lane; m < cnt; m += 64) sum += expf(s_att[m] * s_h[m] - mx);
-  sum = gn_wave_sum(sum);
-  sum += gn_nonmember_sum(N - cnt, mx);
-  // edges[e] = sum_n (softmax_n * H[e,n]) * x'_n ; lane = feature
-  float acc = 0.f;
-  for (int m = 0; m < cnt; ++m) {
-    const float hv = s_h[m];
-    const float wgt = expf(s_att[m] * hv - mx) / sum * hv;
-    acc = fmaf(wgt, ld1(xpb + (size_t)s_idx[m] * GN_FEAT + lane), acc);
-  }
-  if (live) st1(reinterpret_cast<TS*>(G.edges) + (size_t)eg * GN_FEAT + lane, acc);
 }
 
 // Pairwise module (MS_HGNN_oridinary): edge e = i*N + j touches i and j with weight 1 (2 on the
@@ -387,7 +406,7 @@ __device__ __forceinline__ void node2edge_pairwise_body(const gn_n2e_group_t& G,
 }
 
 // One launch for every module of a multiscale forward: the first `pair.first_wg[pair.n]` workgroups walk the
-// pairwise groups (scene-staged), the rest the hyperedges (one wave each).
+// pairwise groups, the rest the hyper groups (both scene-staged).
 struct PairTable {
   gn_n2e_group_t g[GN_MAX_GROUPS];
   int first_wg[GN_MAX_GROUPS + 1];
@@ -395,7 +414,8 @@ struct PairTable {
   int n;
 };
 template <typename TS>
-__global__ __launch_bounds__(kBlock) void node2edge_kernel(WaveTable<gn_n2e_group_t> T, PairTable pair, int B, int N) {
+__global__ __launch_bounds__(kBlock) void node2edge_kernel(WaveTable<gn_n2e_group_t> T, PairTable pair, int B, int N,
+                                                           int SGh) {
   const int wg = blockIdx.x;
   const int n_pair_wgs = pair.first_wg[pair.n];
   if (wg < n_pair_wgs) {
@@ -403,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_kernel(WaveTable<gn_n2e_grou
     while (g + 1 < pair.n && wg >= pair.first_wg[g + 1]) ++g;
     node2edge_pairwise_body<TS>(pair.g[g], B, N, pair.SG[g], pair.bands[g], wg - pair.first_wg[g]);
   } else {
-    node2edge_hyper_body<TS>(T, N, wg - n_pair_wgs);
+    node2edge_hyper_body<TS>(T, B, N, SGh, wg - n_pair_wgs);
   }
 }
 
@@ -902,21 +922,29 @@ static int node2edge_launch(const gn_n2e_group_t* groups, int n_groups, int B, i
     }
     if (G.sym) return GN_ERR_SHAPE;  // the symmetric form exists for the pairwise graph only
     T.g[T.n] = G;
-    T.first[T.n] = waves;
-    waves += (long long)B * G.E;
     ++T.n;
   }
-  T.first[T.n] = waves;
   P.first_wg[P.n] = pair_wgs;
+  // hyper groups: scenes per workgroup so that the staged rows stay <= 32 KiB while the grid keeps >= ~1024 workgroups
+  int SGh = 1;
   if (T.n > 0) {
-    const size_t l = (size_t)(kBlock / 64) * 3 * N * sizeof(float);
-    if (l > kLdsBudget) return GN_ERR_LDS;
+    const size_t per_scene = (size_t)N * (GN_FEAT + GN_FEAT + 1) * sizeof(float);
+    const size_t scratch = (size_t)(kBlock / 64) * 3 * N * sizeof(float);
+    if (per_scene + scratch > 158 * 1024) return GN_ERR_LDS;
+    while (SGh < 8 && (size_t)(2 * SGh) * per_scene <= 32 * 1024 && (long long)((B + 2 * SGh - 1) / (2 * SGh)) * T.n >= 1024)
+      SGh *= 2;
+    const size_t l = (size_t)SGh * per_scene + scratch;
     lds = lds > l ? lds : l;
+    for (int g = 0; g < T.n; ++g) {
+      T.first[g] = waves;
+      waves += (B + SGh - 1) / SGh;                    // (`waves` counts workgroups here)
+    }
   }
-  const long long grid = pair_wgs + (waves + 3) / 4;
+  T.first[T.n] = waves;
+  const long long grid = pair_wgs + waves;
   if (grid > 0x7fffffffLL) return GN_ERR_SHAPE;
   gn_allow_big_lds(node2edge_kernel<TS>);
-  hipLaunchKernelGGL(node2edge_kernel<TS>, dim3((unsigned)grid), dim3(kBlock), lds, s, T, P, B, N);
+  hipLaunchKernelGGL(node2edge_kernel<TS>, dim3((unsigned)grid), dim3(kBlock), lds, s, T, P, B, N, SGh);
   return gn_check_launch();
 }
 extern "C" int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, gn_stream_t stream) {

@@ -53,6 +53,13 @@ struct Parts {
 // bf16 operand(s) of half `hf` of a 32-feature fp32 tile held in a lane's 16 registers
 template <int P>
 __device__ __forceinline__ void make_parts(const f32x16& v, int hf, Parts<P>& x) {
+#ifdef GN_DIAG_NO_SPLIT      // diagnostic builds only: what the kernels take without the VALU splitting work
+  for (int p = 0; p < P; ++p) {
+    const f32x4 w = {v[8 * hf], v[8 * hf + 1], v[8 * hf + 2], v[8 * hf + 3]};
+    x.p[p] = __builtin_bit_cast(bf16x8, w);
+  }
+  return;
+#endif
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) {
     if constexpr (P == 3) {
@@ -75,43 +82,145 @@ __device__ __forceinline__ void make_parts_tiles(const f32x16 (&v)[NT], Parts<P>
   }
 }
 
+// acc += W[sub-step] . x from the sub-step's P 16-byte operand pieces
 template <int P>
-struct XRing {
-#ifndef GN_RING3
-#define GN_RING3 4
+__device__ __forceinline__ void mfma_substep(const f32x4 (&w)[P], const Parts<P>& x, f32x16& acc) {
+#ifdef GN_DIAG_NO_MFMA       // diagnostic builds only: everything but the matrix instructions
+  for (int p = 0; p < P; ++p) acc[p] += w[p][0] * __builtin_bit_cast(f32x4, x.p[p])[0];
+  return;
 #endif
-  static constexpr int D = P == 3 ? GN_RING3 : 16;   // ring depth in sub-steps
-  f32x4 q[D * P];
-  __device__ __forceinline__ void prime(const f32x4* __restrict__ src) {   // src: this lane's pointer at sub-step 0
-#pragma unroll
-    for (int u = 0; u < D * P; ++u) q[u] = src[u * 64];
+  if constexpr (P == 3) {
+    const bf16x8 w1 = __builtin_bit_cast(bf16x8, w[0]);
+    const bf16x8 w2 = __builtin_bit_cast(bf16x8, w[1]);
+    const bf16x8 w3 = __builtin_bit_cast(bf16x8, w[2]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x.p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x.p[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.p[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x.p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.p[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.p[0], acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[0]), x.p[0], acc, 0, 0, 0);
   }
-  // acc += W[sub-step in ring slot s % D] . x, then the slot is refilled from `next` (this lane's pointer at the
-  // sub-step D ahead).  `s` must be a compile-time constant at every call site (fully unrolled callers).
-  // FENCE: close the scheduling region behind the step (the default); a caller that interleaves other work with a
-  // run of steps passes false and fences the run itself.
-  template <bool FENCE = true>
-  __device__ __forceinline__ void step(int s, const Parts<P>& x, f32x16& acc, const f32x4* __restrict__ next) {
-    const int u = (s % D) * P;
-    if constexpr (P == 3) {
-      const bf16x8 w1 = __builtin_bit_cast(bf16x8, q[u + 0]);
-      const bf16x8 w2 = __builtin_bit_cast(bf16x8, q[u + 1]);
-      const bf16x8 w3 = __builtin_bit_cast(bf16x8, q[u + 2]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x.p[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x.p[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.p[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x.p[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.p[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.p[0], acc, 0, 0, 0);
-    } else {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q[u]), x.p[0], acc, 0, 0, 0);
-    }
-#ifndef GN_NO_REFILL     // (diagnostic builds only: what the kernels would take with the weights already in registers)
+}
+
+// ---- a wave's PRIVATE weight stream: a register ring D sub-steps ahead of the matrix pipe, refilled straight from
+// L2.  Used where the waves of a workgroup walk different parts of an image (the typed aggregation with the types
+// dealt over the waves of a row block); everything else shares one stream per workgroup through LDS (WStream).
+// A stream is a sequence of segments (e.g. one per edge type) of `seg` sub-steps at `cur`, followed by `nxt`.
+template <int P>
+struct XStream {
+  static constexpr int D = P == 3 ? 4 : 16;   // ring depth in sub-steps
+  static constexpr int CH = 1;                // (positions are given in sub-steps: c0 is ignored)
+  f32x4 q[D][P];
+  const f32x4* cur;     // this lane's pointer at sub-step 0 of the current segment
+  const f32x4* nxt;     // ... of the segment after it
+  int seg;
+  __device__ __forceinline__ void begin(const f32x4* first) {
 #pragma unroll
-    for (int p = 0; p < P; ++p) q[u + p] = next[p * 64];
-#endif
+    for (int u = 0; u < D; ++u)
+#pragma unroll
+      for (int p = 0; p < P; ++p) q[u][p] = first[(u * P + p) * 64];
+  }
+  __device__ __forceinline__ void segment(const f32x4* cur_, const f32x4* nxt_, int seg_) { cur = cur_, nxt = nxt_, seg = seg_; }
+  template <bool FENCE = true>
+  __device__ __forceinline__ void step(int, int s, const Parts<P>& x, f32x16& acc) {
+    const int u = s % D;
+    mfma_substep<P>(q[u], x, acc);
+    const f32x4* src = s + D < seg ? cur + (size_t)(s + D) * P * 64 : nxt + (size_t)(s + D - seg) * P * 64;
+#pragma unroll
+    for (int p = 0; p < P; ++p) q[u][p] = src[p * 64];
     // hipcc otherwise sinks the run-ahead loads down to their use and collapses the ring
     if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
+  }
+};
+
+// ---- the weight stream of a workgroup, shared through LDS -----------------------------------------------------
+// Every wave of a workgroup walks the SAME weight image (the four 32-row blocks of a workgroup belong to one
+// module).  Read per wave straight from L2, the three 16-byte pieces per k = 16 sub-step are 64 B/clk per CU at
+// full matrix rate — exactly the bandwidth of the CU's vector-memory path, which then, not the matrix pipe, paces
+// the kernel (measured: lone waves at 50-55 % of the MFMA-bound time, 68 % with the loads removed).  So the
+// workgroup fetches the image ONCE: it is cut into chunks of CH sub-steps; each of the 4 waves loads a quarter of
+// every chunk into registers LOOK chunks ahead (ordinary global loads: counted vmcnt waits, nothing drains), writes
+// it into a ring of R = 3 chunks in LDS two chunks before its use, and all waves read their MFMA A operands from
+// there with ds_read_b128 (conflict-free: lane-linear 1-KiB pieces), one sub-step ahead.  One raw barrier per chunk:
+//   boundary(c):  s_waitcnt lgkmcnt(0); s_barrier      -- every wave has finished chunk c-1, chunk c+1 is visible
+//                 chunk c+2  : staging registers -> LDS slot (c+2) % 3   (the slot chunk c-1 occupied)
+//                 chunk c+2+LOOK : global -> staging registers
+// Requirements: all 4 waves of the workgroup call begin / step / skip with identical arguments (no early exits);
+// segment lengths are multiples of CH * LOOK sub-steps wherever the chunk index is not a compile-time constant.
+template <int P>
+struct WStream {
+  static constexpr int CH = P == 3 ? 4 : 8;      // sub-steps per chunk
+  static constexpr int LOOK = P == 3 ? 2 : 4;    // chunks between a piece's global load and its LDS write
+  static constexpr int R = 3;                    // chunks in the LDS ring
+  static constexpr int PIECES = CH * P;          // 1-KiB pieces (64 lanes x 16 B) per chunk
+  static constexpr int PW = PIECES / 4;          // pieces each of the 4 waves stages per chunk
+  static constexpr int kRingF4 = R * PIECES * 64;   // f32x4 elements of the ring (36 KiB / 24 KiB)
+  f32x4* ring;          // LDS ring, this lane's view
+  const f32x4* src;     // global image at this stream's first chunk, this lane's view
+  int last;             // local index of the image's last chunk (loads beyond it are clamped to it)
+  int wave;
+  f32x4 st[LOOK][PW];
+  f32x4 q[2][P];
+
+#ifdef GN_DIAG_NO_BARRIER    // diagnostic builds only (results are wrong)
+  __device__ __forceinline__ static void barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
+  __device__ __forceinline__ static void barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+  __device__ __forceinline__ const f32x4* piece_src(int chunk, int i) const {
+    return src + ((size_t)min(chunk, last) * PIECES + wave * PW + i) * 64;
+  }
+  __device__ __forceinline__ f32x4* piece_dst(int chunk, int i) const {
+    return ring + ((chunk % R) * PIECES + wave * PW + i) * 64;
+  }
+  __device__ __forceinline__ void read_ops(int chunk, int sub, int slot) {
+    const f32x4* p = ring + ((chunk % R) * PIECES + sub * P) * 64;
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) q[slot][pp] = p[pp * 64];
+  }
+  // image: global address of the stream's first chunk; n_chunks: chunks from there to the end of the image
+  __device__ __forceinline__ void begin(const void* image, f32x4* lds_ring, int lane, int wave_, int n_chunks) {
+    ring = lds_ring + lane;
+    src = reinterpret_cast<const f32x4*>(image) + lane;
+    last = n_chunks - 1;
+    wave = wave_;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < PW; ++i) *piece_dst(c, i) = *piece_src(c, i);
+#pragma unroll
+    for (int j = 0; j < LOOK; ++j)
+#pragma unroll
+      for (int i = 0; i < PW; ++i) st[j][i] = *piece_src(2 + j, i);
+    barrier();
+    read_ops(0, 0, 0);
+  }
+  // chunk boundary: `c` = local chunk index (runtime), `cl` = the same modulo LOOK (compile-time)
+  __device__ __forceinline__ void boundary(int c, int cl) {
+    barrier();
+#pragma unroll
+    for (int i = 0; i < PW; ++i) *piece_dst(c + 2, i) = st[cl % LOOK][i];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) st[cl % LOOK][i] = *piece_src(c + 2 + LOOK, i);
+  }
+  // acc += W[sub-step s of the segment that starts at local chunk c0] . x.  `s` is a compile-time constant at every
+  // call site; c0 may be a runtime value (a multiple of LOOK).  FENCE closes the scheduling region behind the step.
+  template <bool FENCE = true>
+  __device__ __forceinline__ void step(int c0, int s, const Parts<P>& x, f32x16& acc) {
+    const int c = c0 + s / CH;
+    if (s % CH == 0) boundary(c, s / CH);
+    read_ops(c0 + (s + 1) / CH, (s + 1) % CH, (s + 1) & 1);      // next sub-step's operands (LDS latency under the MFMAs)
+    mfma_substep<P>(q[s & 1], x, acc);
+    if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
+  }
+  // pass over sub-steps [s, s + n) without using them: the wave still takes part in every chunk boundary among them
+  __device__ __forceinline__ void skip(int c0, int s, int n) {
+#pragma unroll
+    for (int p = s; p < s + n; ++p)
+      if (p % CH == 0) boundary(c0 + p / CH, p / CH);
+    read_ops(c0 + (s + n) / CH, (s + n) % CH, (s + n) & 1);
   }
 };
 
@@ -119,16 +228,16 @@ struct XRing {
 //   out[o] += W1(o, :) post(W0 x + b0)      x: IT input tiles (as parts), HT hidden tiles, OT output tiles
 // A_t = the 2*IT sub-steps that produce hidden tile t, V_t = its VALU work (post: ReLU / scale / optional store,
 // then the bf16 part(s)), B_t = the 2*OT sub-steps that consume it.  B_t needs V_t needs A_t, so executed in that
-// order a lone wave leaves the matrix pipe idle during every V_t (~120 VALU instructions for three parts).  The
+// order a lone wave leaves the matrix pipe idle during every V_t (~100 VALU instructions for three parts).  The
 // pipeline issues A_{t+1} between A_t and B_t and interleaves V_t with its MFMAs (sched_group_barrier: one MFMA,
 // then a few VALU), so the splitting runs in the shadow of the matrix pipe.  The weight image is laid out in this
 // order:  A0 A1 B0 A2 B1 ... A(HT-1) B(HT-2) B(HT-1).  Bias tiles ride two hidden tiles ahead of their use: a
-// load that is waited for right after it is issued would also wait for every run-ahead load of the weight ring
+// load that is waited for right after it is issued would also wait for every staging load of the weight stream
 // (vmcnt counts in order).
-//   pos0: stream position (sub-steps) of A0 — a compile-time constant at the call site; nxt(pos): this lane's
-//   pointer at position pos + D;  hid0: bias tile 0 (loaded early by the caller).
-template <int P, int IT, int OT, int HT, typename NextFn, typename PostFn>
-__device__ __forceinline__ void layer_pair(XRing<P>& ring, int pos0, NextFn nxt, const Parts<P> (&xi)[IT][2],
+//   c0, s0: the segment's first chunk (runtime) and the sub-step of A0 inside it (compile-time);
+//   hid0: bias tile 0 (loaded early by the caller).
+template <int P, int IT, int OT, int HT, typename Stream, typename PostFn>
+__device__ __forceinline__ void layer_pair(Stream& ws, int c0, int s0, const Parts<P> (&xi)[IT][2],
                                            const f32x16& hid0, const float* __restrict__ b0, int h,
                                            f32x16 (&out)[OT], PostFn post) {
   constexpr int NA = 2 * IT, NB = 2 * OT;
@@ -137,13 +246,13 @@ __device__ __forceinline__ void layer_pair(XRing<P>& ring, int pos0, NextFn nxt,
 #define GN_KVALU 96
 #endif
   constexpr int kValu = P == 3 ? (GN_KVALU + kMfma - 1) / kMfma : (40 + kMfma - 1) / kMfma;   // VALU slots per MFMA
-  int pos = pos0;
+  int pos = s0;
   f32x16 hidn = hid0;
   f32x16 bias_n;
   if (HT > 1) bias_n = load_bias_tile(b0 + 32, h);
 #pragma unroll
   for (int u = 0; u < NA; ++u) {
-    ring.step(pos, xi[u >> 1][u & 1], hidn, nxt(pos));
+    ws.step(c0, pos, xi[u >> 1][u & 1], hidn);
     ++pos;
   }
 #pragma unroll
@@ -160,20 +269,21 @@ __device__ __forceinline__ void layer_pair(XRing<P>& ring, int pos0, NextFn nxt,
     if (t + 1 < HT) {
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
-        ring.template step<false>(pos, xi[u >> 1][u & 1], hidn, nxt(pos));
+        ws.template step<false>(c0, pos, xi[u >> 1][u & 1], hidn);
         ++pos;
       }
 #pragma unroll
       for (int i = 0; i < kMfma; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
         __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);      // VALU of V_t in its shadow
-        if (P == 3 ? (i & 1) == 1 : true) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a ring refill
+        if ((i % (P == 3 ? 6 : 1)) == 0)          // the sub-step's operand reads (LDS) / ring refills (global)
+          __builtin_amdgcn_sched_group_barrier(Stream::CH == 1 ? 0x020 : 0x100, P, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      ring.step(pos, xh[u & 1], out[u >> 1], nxt(pos));
+      ws.step(c0, pos, xh[u & 1], out[u >> 1]);
       ++pos;
     }
   }
@@ -191,33 +301,35 @@ __device__ __forceinline__ void store_tile(T* __restrict__ p, const f32x16& a) {
 // ---- node stage: x' = MLP(64->256->64)(x), pq = x' Wpq^T + bpq, and (pairwise module) A = WA x + bA ------------
 // A3 first half (MS_HGNN_batch.py:125,131-134,358,362-365) and the per-node first layer of the typed aggregation
 // MLP of the pairwise graph (MS_HGNN_batch.py:264-265; see gn_node_linear_f32) in ONE launch: both read the same
-// node rows.  Work units, one wave each: a "chain" unit = one 32-row block of one group through the whole chain
-// (72 sub-steps); an "A" unit = one row block x 8 output tiles of WA (32 sub-steps).  Long units first.
+// node rows.  A workgroup = 4 consecutive 32-row blocks of ONE group, one wave each, sharing one weight stream:
+// "chain" workgroups run the whole chain (72 sub-steps), "A" workgroups 8 output tiles of WA (32 sub-steps).
+// Long workgroups first.
 struct NodeTable {
   gn_node_group_t g[GN_MAX_GROUPS];
-  int a_first[GN_MAX_GROUPS + 1];   // prefix of A units per group, relative to chain_units
-  int n, rows, blocks32, chain_units, total_units;
+  int a_first[GN_MAX_GROUPS + 1];   // prefix of A workgroups per group, relative to chain_wgs
+  int n, rows, wgs_per_group, chain_wgs;
 };
-constexpr int kATiles = 8;   // output tiles of WA per A unit
+constexpr int kATiles = 8;   // output tiles of WA per A workgroup
 
 template <int P, typename T>
 __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
-  constexpr int D = XRing<P>::D;
-  const int unit = blockIdx.x * 4 + wave_id();
-  if (unit >= Tb.total_units) return;
+  using WS = WStream<P>;
+  __shared__ f32x4 wring[WS::kRingF4];
+  const int wave = wave_id();
   const int lane = threadIdx.x & 63, h = lane >> 5;
-  if (unit < Tb.chain_units) {
-    const int gi = gn_uniform(unit / Tb.blocks32);
+  const int wg = blockIdx.x;
+  WS ws;
+  if (wg < Tb.chain_wgs) {
+    const int gi = gn_uniform(wg / Tb.wgs_per_group);
     const gn_node_group_t G = Tb.g[gi];
-    const RowBlock rb = row_block(Tb.rows, unit - gi * Tb.blocks32);
+    const RowBlock rb = row_block(Tb.rows, (wg - gi * Tb.wgs_per_group) * 4 + wave);
+    const int unit = wg * 4 + wave;
     GN_STAMP(unit, 0);
     GN_STAMP(unit, 8);
     const float* b0 = G.bias;
     const float* b1 = G.bias + 256;
     const float* bpq = G.bias + 320;
-    const f32x4* Wx = reinterpret_cast<const f32x4*>(G.Wx) + lane;
-    XRing<P> ring;
-    ring.prime(Wx);
+    ws.begin(G.Wx, wring, lane, wave, 72 / WS::CH);
     f32x16 in[2];
     load_rows<2>(reinterpret_cast<const T*>(G.x), GN_FEAT, rb.row_ld, h, in);
     const f32x16 hid0 = load_bias_tile(b0, h);
@@ -229,11 +341,9 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
     Parts<P> xi[2][2];
     make_parts_tiles<P, 2>(in, xi);
     GN_STAMP(unit, 1);
-    constexpr int kSub = 72;
-    auto nxt = [&](int s) { return Wx + (size_t)(s + D < kSub ? s + D : s + D - kSub) * P * 64; };
     // image: the 64->256->64 pair in pipeline order (A_t = [W0(t,in0), W0(t,in1)], B_t = [W1(0,t), W1(1,t)]), then
     // [Wpq(0,in0), Wpq(0,in1), Wpq(1,in0), Wpq(1,in1)]
-    layer_pair<P, 2, 2, 8>(ring, 0, nxt, xi, hid0, b0, h, xp, [&](int t, f32x16& hid) {
+    layer_pair<P, 2, 2, 8>(ws, 0, 0, xi, hid0, b0, h, xp, [&](int t, f32x16& hid) {
       relu16(hid);
       if (G.hid_out != nullptr && rb.live) store_tile(G.hid_out + (size_t)rb.row * 256 + 32 * t + 4 * h, hid);
     });
@@ -242,43 +352,37 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
     Parts<P> xq[2][2];
     make_parts_tiles<P, 2>(xp, xq);
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      const int s = 64 + 4 * o;
-      ring.step(s + 0, xq[0][0], pq[o], nxt(s + 0));
-      ring.step(s + 1, xq[0][1], pq[o], nxt(s + 1));
-      ring.step(s + 2, xq[1][0], pq[o], nxt(s + 2));
-      ring.step(s + 3, xq[1][1], pq[o], nxt(s + 3));
-    }
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ws.step(0, 64 + 4 * o + i, xq[i >> 1][i & 1], pq[o]);
     GN_STAMP(unit, 3);
     store_rows<2>(reinterpret_cast<T*>(G.pq), GN_FEAT, rb.row, h, rb.live, pq);
     GN_STAMP(unit, 4);
     GN_STAMP(unit, 9);
     return;
   }
-  // ---- A unit ----
-  const int v = unit - Tb.chain_units;
+  // ---- A workgroup: (output-tile chunk c, 4 row blocks) ----
+  const int v = wg - Tb.chain_wgs;
   int gi = 0;
   while (gi + 1 < Tb.n && v >= Tb.a_first[gi + 1]) ++gi;
   gi = gn_uniform(gi);
   const gn_node_group_t G = Tb.g[gi];
   const int OTA = 4 * G.KA;                              // output tiles of WA (128 per type)
-  const int chunks = (OTA + kATiles - 1) / kATiles;
   const int local = v - Tb.a_first[gi];
-  const int blk = local / chunks, c = local - blk * chunks;
-  const RowBlock rb = row_block(Tb.rows, blk);
+  const int c = local / Tb.wgs_per_group, quad = local - c * Tb.wgs_per_group;
+  const RowBlock rb = row_block(Tb.rows, quad * 4 + wave);
+  const int unit = wg * 4 + wave;
   GN_STAMP(unit, 0);
   GN_STAMP(unit, 8);
+  const int o0 = c * kATiles;
+  const int nt = min(kATiles, OTA - o0);                 // a multiple of 4
+  // 4 sub-steps per output tile; the stream of this workgroup starts at tile o0 of the image
+  ws.begin(reinterpret_cast<const f32x4*>(G.WAx) + (size_t)o0 * 4 * P * 64, wring, lane, wave, (OTA - o0) * 4 / WS::CH);
   f32x16 in[2];
   load_rows<2>(reinterpret_cast<const T*>(G.x), GN_FEAT, rb.row_ld, h, in);
   Parts<P> xi[2][2];
   make_parts_tiles<P, 2>(in, xi);
   GN_STAMP(unit, 1);
-  const int o0 = c * kATiles;
-  const int nt = min(kATiles, OTA - o0);                 // a multiple of 4
-  const int nsub = 4 * nt;
-  const f32x4* Wa = reinterpret_cast<const f32x4*>(G.WAx) + lane + (size_t)o0 * 4 * P * 64;
-  XRing<P> ring;
-  ring.prime(Wa);
   const size_t ldA = (size_t)OTA * 32;
   T* arow = reinterpret_cast<T*>(G.A) + (size_t)rb.row * ldA + 4 * h;
   f32x16 bn = load_bias_tile(G.bA + 32 * o0, h);          // bias rides one tile ahead (see layer_pair)
@@ -290,11 +394,7 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
       f32x16 acc = bn;
       bn = load_bias_tile(G.bA + 32 * min(o + 1, o0 + nt - 1), h);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int s = 4 * oo + i;                        // ring slot: 16 sub-steps per iteration of the outer loop
-        const int sg = 4 * o4 + s + D;
-        ring.step(s, xi[i >> 1][i & 1], acc, Wa + (size_t)(sg < nsub ? sg : sg - nsub) * P * 64);
-      }
+      for (int i = 0; i < 4; ++i) ws.step(o4 * 4 / WS::CH, 4 * oo + i, xi[i >> 1][i & 1], acc);   // 16 sub-steps per pass
       if (rb.live) store_tile(arow + 32 * o, acc);
     }
   }
@@ -309,13 +409,13 @@ template <int P, typename T>
 __global__ __launch_bounds__(256, 2) void edge_x_kernel(GroupTable<gn_edge_group_t> Tb, float tau,
                                                         unsigned long long seed,
                                                         const unsigned long long* __restrict__ offset_dev) {
-  constexpr int D = XRing<P>::D;
+  using WS = WStream<P>;
+  __shared__ f32x4 wring[WS::kRingF4];
   const int gi = find_group(Tb, blockIdx.x);
   const gn_edge_group_t G = Tb.g[gi];
   const int rows = G.rows, K = G.K;
   const int blk = (blockIdx.x - Tb.first_wg[gi]) * 4 + wave_id();
-  if (blk * 32 >= rows) return;
-  const RowBlock rb = row_block(rows, blk);
+  const RowBlock rb = row_block(rows, blk);      // (a wave past the group's rows works on a clamped row, stores nothing)
   const int lane = rb.lane, h = rb.h;
   const int unit = blockIdx.x * 4 + wave_id();
   GN_STAMP(unit, 0);
@@ -341,11 +441,8 @@ __global__ __launch_bounds__(256, 2) void edge_x_kernel(GroupTable<gn_edge_group
   const float* bi1 = G.bias + 128;
   const float* bd0 = G.bias + 192;
   const float* bd1 = G.bias + 448;
-  const f32x4* Wx = reinterpret_cast<const f32x4*>(G.Wx) + lane;
-  XRing<P> ring;
-  ring.prime(Wx);
-  constexpr int kSub = 80;
-  auto nxt = [&](int s) { return Wx + (size_t)(s + D < kSub ? s + D : s + D - kSub) * P * 64; };
+  WS ws;
+  ws.begin(G.Wx, wring, lane, wave_id(), 80 / WS::CH);
   const f32x16 hidA0 = load_bias_tile(bi0, h);
   const f32x16 hidB0 = load_bias_tile(bd0, h);
   z[0] = load_bias_tile(bi1, h);
@@ -356,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void edge_x_kernel(GroupTable<gn_edge_group
   make_parts_tiles<P, 2>(in, xi);
   GN_STAMP(unit, 1);
   // ---- pair A: 64 -> 128 -> 64, 4 hidden tiles x (4 + 4) sub-steps, pipeline order ----
-  layer_pair<P, 2, 2, 4>(ring, 0, nxt, xi, hidA0, bi0, h, z, [&](int t, f32x16& hid) {
+  layer_pair<P, 2, 2, 4>(ws, 0, 0, xi, hidA0, bi0, h, z, [&](int t, f32x16& hid) {
     relu16(hid);
     if (G.keep_z1 != nullptr && rb.live) store_tile(G.keep_z1 + (size_t)rb.row * 128 + 32 * t + 4 * h, hid);
   });
@@ -364,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void edge_x_kernel(GroupTable<gn_edge_group
   if (G.keep_z != nullptr) store_rows<2>(G.keep_z, GN_FEAT, rb.row, h, rb.live, z);
   make_parts_tiles<P, 2>(z, xi);
   // ---- pair B: 64 -> 256 -> (logits | factor), 8 hidden tiles x (4 + 2) sub-steps, pipeline order ----
-  layer_pair<P, 2, 1, 8>(ring, 32, nxt, xi, hidB0, bd0, h, lgv, [&](int t, f32x16& hid) {
+  layer_pair<P, 2, 1, 8>(ws, 0, 32, xi, hidB0, bd0, h, lgv, [&](int t, f32x16& hid) {
     relu16(hid);
     if (G.keep_dh1 != nullptr && rb.live) store_tile(G.keep_dh1 + (size_t)rb.row * 256 + 32 * t + 4 * h, hid);
   });
@@ -436,7 +533,9 @@ __device__ __forceinline__ void add_b2(const float* __restrict__ b2k, float efk,
 
 template <int P, typename T>
 __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) {
-  constexpr int D = XRing<P>::D;
+  using WS = WStream<P>;
+  constexpr int CH = WS::CH;
+  __shared__ f32x4 wring[WS::kRingF4];
   __shared__ float part[4][32][64 + 8];   // wpr > 1: [wave][register 0..31][lane]; staged pair form: 2 x node rows
   const int gi = find_group(Tb, blockIdx.x);
   const gn_agg_group_t G = Tb.g[gi].a;
@@ -444,12 +543,16 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
   const int rows = G.rows, K = G.K;
   const int wave = wave_id();
   const int wg = blockIdx.x - Tb.first_wg[gi];
-  const int sub = wave % wpr;                       // which share of the types
-  const int blk = wg * (4 / wpr) + wave / wpr;      // which row block
+  // wpr == 1: every wave owns a 32-row block and walks all K types; the workgroup's 4 waves share ONE weight stream
+  //           through LDS (WStream);
+  // wpr  > 1: wpr waves share one row block (groups with few row blocks: shorter critical path), wave `sub` of them
+  //           takes the types sub, sub + wpr, ... through a private register ring (XStream), the partial sums meet
+  //           in LDS.
+  const int sub = wave % wpr;
+  const int blk = wg * (4 / wpr) + wave / wpr;
   const bool any_rows = blk * 32 < rows;
   const bool staged = Tb.g[gi].stage != 0;
-  if (wpr == 1 && !any_rows && !staged) return;     // (a staged workgroup keeps all its waves for the barriers)
-  const RowBlock rb = row_block(rows, any_rows ? blk : 0);
+  const RowBlock rb = row_block(rows, any_rows ? blk : 0);     // (no early exit: every wave takes part in the barriers)
   const int lane = rb.lane, h = rb.h;
   f32x16 out[2];
 #pragma unroll
@@ -459,17 +562,18 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
   const float* efrow = G.edge_feat + (size_t)rb.row_ld * K;
   const float* b1 = G.b1;
   const float* b2 = G.b2;
-  XRing<P> ring;
+  WS ws;
   const int unit = blockIdx.x * 4 + wave;
   GN_STAMP(unit, 0);
   GN_STAMP(unit, 8);
 
   bool pair_form = false;
   if constexpr (P == 3) pair_form = G.A != nullptr;
-  if (pair_form) {
-    // ---- pair form: hid_t = relu(A_i + A_j) * ef_k is VALU work (V_t), its layer-2 slice the matrix work (B_t).
-    // Pipelined: V of the NEXT tile (the next type's tile 0 after t == 3) is interleaved with the MFMAs of B_t, the
-    // pre-activations it needs were loaded one tile earlier still.
+  if (pair_form && wpr == 1) {
+    // ---- pair form: hid_t = relu(A_i + A_j) * ef_k is VALU work (V_t), its layer-2 slice the matrix work (B_t:
+    // one chunk of the stream, 16 sub-steps per type).  wpr == 1, pipelined: V of the NEXT tile (the next type's
+    // tile 0 after t == 3) is interleaved with the MFMAs of B_t; the pre-activations it needs were loaded one tile
+    // earlier still.
     const int N = G.N, Pn = G.E;
     int i, j;
     {
@@ -480,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
     }
     const size_t ldA = (size_t)K * 128;
     const T* Abase = reinterpret_cast<const T*>(G.A);
-    const f32x4* Wx = reinterpret_cast<const f32x4*>(G.W2x) + lane;   // sub-step s of type k: (k*16 + s)
+    ws.begin(G.W2x, wring, lane, wave, K * 16 / CH);
     auto hidden = [&](const PreTile& pa, const PreTile& pb, float efk, Parts<P> (&xh)[2]) {
       f32x16 hid;
 #pragma unroll
@@ -491,20 +595,19 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
       make_parts<P>(hid, 1, xh[1]);
     };
     // B_t with the next tile's V in its shadow
-    auto slice = [&](int t, const Parts<P> (&xh)[2], const f32x4* cur, const f32x4* nx, const PreTile& pa,
-                     const PreTile& pb, float ef_next, Parts<P> (&xh_next)[2]) {
+    auto slice = [&](int c0, int t, const Parts<P> (&xh)[2], PreTile& pa, PreTile& pb, float ef_next,
+                     Parts<P> (&xh_next)[2], auto na, auto nb_) {
       hidden(pa, pb, ef_next, xh_next);
+      pa = load_pre(na, h);          // the tile after the next one (LDS)
+      pb = load_pre(nb_, h);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int s = 4 * t + u;                      // [W2(0,t) hf0, hf1, W2(1,t) hf0, hf1]
-        const f32x4* src = s + D < 16 ? cur + (size_t)(s + D) * P * 64 : nx + (size_t)(s + D - 16) * P * 64;
-        ring.template step<false>(s, xh[u & 1], out[u >> 1], src);
-      }
+      for (int u = 0; u < 4; ++u)                    // [W2(0,t) hf0, hf1, W2(1,t) hf0, hf1]
+        ws.template step<false>(c0, 4 * t + u, xh[u & 1], out[u >> 1]);
 #pragma unroll
       for (int m = 0; m < 24; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-        if (m & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (m % 6 == 0) __builtin_amdgcn_sched_group_barrier(0x100, P, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -534,7 +637,6 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
         }
       };
       const int oi = (i - node0) * kStagePitch, oj = (j - node0) * kStagePitch;
-      ring.prime(Wx);
       fetch(0);
       commit(0);
       fetch(K > 1 ? 1 : 0);
@@ -554,65 +656,117 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
         if (k + 1 < K) commit((k + 1) & 1);                   // (that buffer was last read during type k - 1)
         if (k + 2 < K) fetch(k + 2);
         add_b2(b2 + k * 64, efk, lane, h, out);
-        const f32x4* cur = Wx + (size_t)k * 16 * P * 64;
-        const f32x4* nx = Wx + (size_t)kc * 16 * P * 64;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          // pa/pb hold tile t+1 (tile 0 of the next type when t == 3); fetch the one after it
-          const PreTile qa = pa, qb = pb;
-          if (t == 2) __syncthreads();                        // the next type's rows are committed by every wave
-          if (t < 2) {
-            pa = load_pre(cb + oi + 32 * (t + 2), h);
-            pb = load_pre(cb + oj + 32 * (t + 2), h);
-          } else {
-            pa = load_pre(nb + oi + 32 * (t - 2), h);
-            pb = load_pre(nb + oj + 32 * (t - 2), h);
-          }
+          // pa/pb hold tile t+1 (tile 0 of the next type when t == 3); fetch the one after it.  The stream's chunk
+          // boundary at the head of tile 2 is a workgroup barrier behind the commit above: the next type's rows
+          // are visible from there on.
+          if (t == 2) __syncthreads();
+          const float* nsrc = t < 2 ? cb + 32 * (t + 2) : nb + 32 * (t - 2);
           Parts<P> xn[2];
-          slice(t, xh, cur, nx, qa, qb, t < 3 ? efk : efk_next, xn);
+          slice(k * 16 / CH, t, xh, pa, pb, t < 3 ? efk : efk_next, xn, nsrc + oi, nsrc + oj);
           xh[0] = xn[0];
           xh[1] = xn[1];
         }
         efk = efk_next;
       }
-      if (!any_rows) return;
-    } else if (any_rows && sub < K) {
+    } else if (wpr == 1) {
+      // the rows do not fit the LDS stage: pre-activations straight from HBM / L2, same pipeline
       const T* Ai = Abase + (size_t)i * ldA;
       const T* Aj = Abase + (size_t)j * ldA;
-      int k = sub;
-      ring.prime(Wx + (size_t)k * 16 * P * 64);
-      float efk = efrow[k];
+      float efk = efrow[0];
       Parts<P> xh[2];
-      PreTile pa = load_pre(Ai + k * 128, h), pb = load_pre(Aj + k * 128, h);
+      PreTile pa = load_pre(Ai, h), pb = load_pre(Aj, h);
       hidden(pa, pb, efk, xh);
-      pa = load_pre(Ai + k * 128 + 32, h);
-      pb = load_pre(Aj + k * 128 + 32, h);
+      pa = load_pre(Ai + 32, h);
+      pb = load_pre(Aj + 32, h);
 #pragma unroll 1
-      while (k < K) {
-        const int kn = k + wpr;
-        const int kc = kn < K ? kn : k;
+      for (int k = 0; k < K; ++k) {
+        const int kc = k + 1 < K ? k + 1 : k;
         const float efk_next = efrow[kc];
         add_b2(b2 + k * 64, efk, lane, h, out);
-        const f32x4* cur = Wx + (size_t)k * 16 * P * 64;
-        const f32x4* nx = Wx + (size_t)kc * 16 * P * 64;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const PreTile qa = pa, qb = pb;
           const int off = t < 2 ? k * 128 + 32 * (t + 2) : kc * 128 + 32 * (t - 2);
-          pa = load_pre(Ai + off, h);
-          pb = load_pre(Aj + off, h);
           Parts<P> xn[2];
-          slice(t, xh, cur, nx, qa, qb, t < 3 ? efk : efk_next, xn);
+          slice(k * 16 / CH, t, xh, pa, pb, t < 3 ? efk : efk_next, xn, Ai + off, Aj + off);
           xh[0] = xn[0];
           xh[1] = xn[1];
         }
         efk = efk_next;
-        k = kn;
       }
     }
+  } else if (pair_form) {
+    // ---- pair form, wpr > 1: types dealt over the waves of a row block, private register rings ----------------------
+    if (any_rows && sub < K) {
+      const int N = G.N, Pn = G.E;
+      int i, j;
+      {
+        const int b = rb.row_ld / Pn, p = rb.row_ld - b * Pn;
+        gn_pair_decode(p, N, i, j);
+        i += b * N;
+        j += b * N;
+      }
+      const size_t ldA = (size_t)K * 128;
+      const T* Ai = reinterpret_cast<const T*>(G.A) + (size_t)i * ldA;
+      const T* Aj = reinterpret_cast<const T*>(G.A) + (size_t)j * ldA;
+      const f32x4* Wx = reinterpret_cast<const f32x4*>(G.W2x) + lane;   // sub-step s of type k: (k*16 + s)
+      XStream<P> xs;
+      xs.begin(Wx + (size_t)sub * 16 * P * 64);
+#pragma unroll 1
+      for (int k = sub; k < K; k += wpr) {
+        const int kc = k + wpr < K ? k + wpr : k;
+        const float efk = efrow[k];
+        xs.segment(Wx + (size_t)k * 16 * P * 64, Wx + (size_t)kc * 16 * P * 64, 16);
+        add_b2(b2 + k * 64, efk, lane, h, out);
+        PreTile pa = load_pre(Ai + k * 128, h), pb = load_pre(Aj + k * 128, h);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f32x16 hid;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hid[4 * q + c] = fmaxf(pa.v[q][c] + pb.v[q][c], 0.f) * efk;
+          if (t < 3) {
+            pa = load_pre(Ai + k * 128 + 32 * (t + 1), h);
+            pb = load_pre(Aj + k * 128 + 32 * (t + 1), h);
+          }
+          Parts<P> xh[2];
+          make_parts<P>(hid, 0, xh[0]);
+          make_parts<P>(hid, 1, xh[1]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xs.step(0, 4 * t + u, xh[u & 1], out[u >> 1]);
+        }
+      }
+    }
+  } else if (wpr == 1) {
+    // ---- two-layer form, hidden tile by hidden tile (32 sub-steps per type, pipeline order A0 A1 B0 A2 B1 A3 B2 B3:
+    // A_t = tile t of layer 1 (4 sub-steps), ReLU * ef_k, its bf16 part(s), B_t = its contribution to both output
+    // tiles (4 sub-steps)) — one hidden tile live --------------------------------------------------------------
+    f32x16 in[2];
+    if (G.eo != nullptr)
+      load_rows<2>(reinterpret_cast<const T*>(G.eo), GN_FEAT, rb.row_ld, h, in);
+    else
+      gather_rows<T>(G, rb.row_ld, h, in);
+    Parts<P> xi[2][2];
+    make_parts_tiles<P, 2>(in, xi);
+    GN_STAMP(unit, 1);
+    ws.begin(G.W12x, wring, lane, wave, K * 32 / CH);
+    f32x16 hid0 = load_bias_tile(b1, h);
+    float efk = efrow[0];
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+      const int kc = k + 1 < K ? k + 1 : k;
+      const float efk_next = efrow[kc];
+      const f32x16 hid0_next = load_bias_tile(b1 + kc * 128, h);
+      add_b2(b2 + k * 64, efk, lane, h, out);
+      layer_pair<P, 2, 2, 4>(ws, k * 32 / CH, 0, xi, hid0, b1 + k * 128, h, out,
+                             [&](int, f32x16& hid) { relu_scale16(hid, efk); });
+      hid0 = hid0_next;
+      efk = efk_next;
+    }
   } else if (any_rows && sub < K) {
-    // ---- two-layer form, hidden tile by hidden tile: tile o of layer 1 (4 sub-steps), ReLU * ef_k, its bf16
-    // part(s), then its contribution to both output tiles (4 sub-steps) — one hidden tile live ----------------------
+    // ---- two-layer form, wpr > 1: types dealt over the waves of a row block, private register rings ------------------
     f32x16 in[2];
     if (G.eo != nullptr)
       load_rows<2>(reinterpret_cast<const T*>(G.eo), GN_FEAT, rb.row_ld, h, in);
@@ -622,35 +776,29 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
     make_parts_tiles<P, 2>(in, xi);
     GN_STAMP(unit, 1);
     const f32x4* Wx = reinterpret_cast<const f32x4*>(G.W12x) + lane;   // sub-step s of type k: (k*32 + s)
-    int k = sub;
-    ring.prime(Wx + (size_t)k * 32 * P * 64);
-    f32x16 hid0 = load_bias_tile(b1 + k * 128, h);
-    float efk = efrow[k];
+    XStream<P> xs;
+    xs.begin(Wx + (size_t)sub * 32 * P * 64);
+    f32x16 hid0 = load_bias_tile(b1 + sub * 128, h);
 #pragma unroll 1
-    while (k < K) {
-      const int kn = k + wpr;
-      const int kc = kn < K ? kn : k;
-      const f32x4* cur = Wx + (size_t)k * 32 * P * 64;
-      const f32x4* nx = Wx + (size_t)kc * 32 * P * 64;
-      const float efk_next = efrow[kc];
+    for (int k = sub; k < K; k += wpr) {
+      const int kc = k + wpr < K ? k + wpr : k;
+      const float efk = efrow[k];
       const f32x16 hid0_next = load_bias_tile(b1 + kc * 128, h);
+      xs.segment(Wx + (size_t)k * 32 * P * 64, Wx + (size_t)kc * 32 * P * 64, 32);
       add_b2(b2 + k * 64, efk, lane, h, out);
-      auto src = [&](int s) { return s + D < 32 ? cur + (size_t)(s + D) * P * 64 : nx + (size_t)(s + D - 32) * P * 64; };
-      layer_pair<P, 2, 2, 4>(ring, 0, src, xi, hid0, b1 + k * 128, h, out,
-                             [&](int, f32x16& hid) { relu_scale16(hid, efk); });
+      layer_pair<P, 2, 2, 4>(xs, 0, 0, xi, hid0, b1 + k * 128, h, out, [&](int, f32x16& hid) { relu_scale16(hid, efk); });
       hid0 = hid0_next;
-      efk = efk_next;
-      k = kn;
     }
   }
   T* feat = reinterpret_cast<T*>(G.feat);
   GN_STAMP(unit, 2);
   if (wpr == 1) {
-    store_rows<2>(feat, GN_FEAT, rb.row, h, rb.live, out);
+    store_rows<2>(feat, GN_FEAT, rb.row, h, rb.live && any_rows, out);
     GN_STAMP(unit, 4);
     GN_STAMP(unit, 9);
     return;
   }
+  __syncthreads();      // (the staged node rows share `part`; not used together with wpr > 1, but keep the order explicit)
 #pragma unroll
   for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -682,37 +830,38 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
 // Image, hidden-tile-major: per hidden tile t the tiles [W0(t, in 0..IT-1), W1(0..OT-1, t)].  Input rows read from
 // x or formed on the fly (fused scatter, IT == 4) exactly as in mlp2_kernel.  blockIdx.y = group.
 template <int P, typename T, int IT, int HT, int OT>
-__global__ __launch_bounds__(256, (P == 3 && IT == 4) ? 1 : 2) void mlp2_x_kernel(GroupTable<gn_mlp2_group_t> Tb, int rows, int dout, int ldy,
+__global__ __launch_bounds__(256, IT == 4 ? 1 : 2) void mlp2_x_kernel(GroupTable<gn_mlp2_group_t> Tb, int rows, int dout, int ldy,
                                                         int N, float divisor) {
-  constexpr int D = XRing<P>::D;
+  using WS = WStream<P>;
+  __shared__ f32x4 wring[WS::kRingF4];
   const int blk = blockIdx.x * 4 + wave_id();
-  if (blk * 32 >= rows) return;
   const gn_mlp2_group_t G = Tb.g[blockIdx.y];
-  const RowBlock rb = row_block(rows, blk);
+  const RowBlock rb = row_block(rows, blk);      // (a wave past the rows works on a clamped row, stores nothing)
   const int lane = rb.lane, h = rb.h;
   const int unit = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave_id();
   GN_STAMP(unit, 0);
   GN_STAMP(unit, 8);
-  const f32x4* Wx = reinterpret_cast<const f32x4*>(G.Wx) + lane;
-  XRing<P> ring;
-  ring.prime(Wx);
+  constexpr int kSub = HT * (2 * IT + 2 * OT);
+  static_assert(kSub % WS::CH == 0, "the image must be a whole number of chunks");
   const float* b0 = G.bias;
   const float* b1 = G.bias + 32 * HT;
   const f32x16 hid0 = load_bias_tile(b0, h);
   f32x16 out[OT];
 #pragma unroll
   for (int o = 0; o < OT; ++o) out[o] = load_bias_tile(b1 + 32 * o, h);
+  WS ws;
   Parts<P> xi[IT][2];
   {
+    // the input rows (a gather over the previous kernel's output: long latencies) are requested first; the first
+    // chunks of the weight stream arrive in their shadow
     f32x16 in[IT];
     mlp2_rows<IT, T>(G, rb.row_ld, h, N, divisor, in);
+    ws.begin(G.Wx, wring, lane, wave_id(), kSub / WS::CH);
     if (G.in_out != nullptr) store_rows<IT>(G.in_out, 32 * IT, rb.row, h, rb.live, in);   // kept for the backward
     make_parts_tiles<P, IT>(in, xi);
   }
   GN_STAMP(unit, 1);
-  constexpr int kSub = HT * (2 * IT + 2 * OT);
-  auto nxt = [&](int s) { return Wx + (size_t)(s + D < kSub ? s + D : s + D - kSub) * P * 64; };
-  layer_pair<P, IT, OT, HT>(ring, 0, nxt, xi, hid0, b0, h, out, [&](int t, f32x16& hid) {
+  layer_pair<P, IT, OT, HT>(ws, 0, 0, xi, hid0, b0, h, out, [&](int t, f32x16& hid) {
     relu16(hid);
     if (G.hid_out != nullptr && rb.live) store_tile(G.hid_out + (size_t)rb.row * (32 * HT) + 32 * t + 4 * h, hid);
   });

@@ -198,6 +198,44 @@ __device__ __forceinline__ void add_row(const T* __restrict__ src, float w, int 
       a[t][4 * q + 3] = fmaf(w, v[3], a[t][4 * q + 3]);
     }
 }
+// a += sum_m w[m] * rows[m] over the m < count with w[m] != 0, where w[m] = wptr[m * wstride] (a row or a column of an
+// incidence matrix) and rows[m] = base + m * GN_FEAT.  Every lane has its own weights.  A loop "load w, branch, load
+// row, accumulate" pays one memory latency per member; instead the nonzero pattern is collected first (independent
+// loads, 8 at a time, a 64-bit mask per lane) and the members are then fetched four at a time (32 loads in flight);
+// lanes with fewer members ride along with weight 0.  count > 64 falls back to the plain loop.
+template <typename T>
+__device__ __forceinline__ void weighted_rows(const float* __restrict__ wptr, int wstride, int count,
+                                              const T* __restrict__ base, int h, f32x16 (&a)[2]) {
+  if (count > 64) {
+    for (int m = 0; m < count; ++m) {
+      const float w = wptr[(size_t)m * wstride];
+      if (w != 0.f) add_row(base + (size_t)m * GN_FEAT, w, h, a);
+    }
+    return;
+  }
+  unsigned long long mask = 0ull;
+  for (int m0 = 0; m0 < count; m0 += 8) {
+    float w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = m0 + u < count ? wptr[(size_t)(m0 + u) * wstride] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mask |= (unsigned long long)(w[u] != 0.f) << (m0 + u);
+  }
+  while (__any(mask != 0ull)) {
+    int m[4];
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = mask != 0ull;
+      m[u] = ok ? __builtin_ctzll(mask) : 0;
+      mask &= mask - 1ull;                       // (0 stays 0)
+      w[u] = ok ? wptr[(size_t)m[u] * wstride] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) add_row(base + (size_t)m[u] * GN_FEAT, w[u], h, a);
+  }
+}
+
 template <typename T = float>
 __device__ __forceinline__ void gather_rows(const gn_agg_group_t& G, int row, int h, f32x16 (&a)[2]) {
   const int E = G.E, N = G.N;
@@ -218,11 +256,7 @@ __device__ __forceinline__ void gather_rows(const gn_agg_group_t& G, int row, in
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) a[t][r] = 0.f;
-    const float* hrow = G.H + (size_t)row * N;
-    for (int n = 0; n < N; ++n) {
-      const float hv = hrow[n];
-      if (hv != 0.f) add_row(ob + (size_t)n * GN_FEAT, hv, h, a);
-    }
+    weighted_rows(G.H + (size_t)row * N, 1, N, ob, h, a);
   }
 }
 
@@ -263,11 +297,7 @@ __device__ __forceinline__ void mlp2_rows(const gn_mlp2_group_t& G, int row, int
       }
       for (; e < E; ++e) add_row(fb + (size_t)e * GN_FEAT, hcol[(size_t)e * N], h, acc);
     } else if (G.H != nullptr) {
-      const float* hcol = G.H + (size_t)b * E * N + n;
-      for (int e = 0; e < E; ++e) {
-        const float hv = hcol[(size_t)e * N];
-        if (hv != 0.f) add_row(fb + (size_t)e * GN_FEAT, hv, h, acc);
-      }
+      weighted_rows(G.H + (size_t)b * E * N + n, N, E, fb, h, acc);
     } else if (G.sym) {
       int j = 0;
       for (; j + 4 <= N; j += 4) {

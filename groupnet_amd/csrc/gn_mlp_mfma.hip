@@ -850,27 +850,26 @@ static int node_stage_launch(const gn_node_group_t* groups, int n_groups, int ro
   NodeTable Tb{};
   Tb.n = n_groups;
   Tb.rows = rows;
-  Tb.blocks32 = (rows + 31) / 32;
-  Tb.chain_units = n_groups * Tb.blocks32;
-  int a_units = 0;
+  Tb.wgs_per_group = (rows + 127) / 128;          // 4 row blocks of one group per workgroup
+  Tb.chain_wgs = n_groups * Tb.wgs_per_group;
+  int a_wgs = 0;
   for (int g = 0; g < n_groups; ++g) {
     const gn_node_group_t& G = groups[g];
     const void* ptrs[] = {G.x, G.Wx, G.bias, G.xp, G.pq};
     for (const void* p : ptrs) GN_CHECK(need(p, true));
     if (P == 1 && G.hid_out != nullptr) return GN_ERR_SHAPE;   // the twins are forward-only
-    Tb.a_first[g] = a_units;
+    Tb.a_first[g] = a_wgs;
     if (G.A != nullptr) {
       GN_CHECK(need(G.WAx, true));
       GN_CHECK(need(G.bA, true));
       GN_CHECK(need(G.A, true));
       if (G.KA < 1 || G.KA > GN_MAX_TYPES) return GN_ERR_SHAPE;
-      a_units += Tb.blocks32 * ((4 * G.KA + kATiles - 1) / kATiles);
+      a_wgs += Tb.wgs_per_group * ((4 * G.KA + kATiles - 1) / kATiles);
     }
     Tb.g[g] = G;
   }
-  Tb.a_first[n_groups] = a_units;
-  Tb.total_units = Tb.chain_units + a_units;
-  hipLaunchKernelGGL((node_stage_kernel<P, T>), dim3((Tb.total_units + 3) / 4), dim3(256), 0, s, Tb);
+  Tb.a_first[n_groups] = a_wgs;
+  hipLaunchKernelGGL((node_stage_kernel<P, T>), dim3(Tb.chain_wgs + a_wgs), dim3(256), 0, s, Tb);
   return gn_check_launch();
 }
 
