@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/groupnet_hip.h"
 
@@ -95,6 +96,50 @@ __device__ __forceinline__ float gn_philox_uniform_at(unsigned long long idx, un
   const int l = (int)(idx & 3);
   const uint32_t x = l == 0 ? c[0] : (l == 1 ? c[1] : (l == 2 ? c[2] : c[3]));
   return gn_philox_to_uniform(x);
+}
+
+// ---- XCD-aware workgroup order ---------------------------------------------------------------------------------
+// The hardware deals the workgroups of a launch round-robin over the 8 XCDs (block p runs on the XCD of p % 8), and
+// every XCD has its own 4 MiB L2.  Every stage of the forward is a set of SECTIONS (one per module, or per module and
+// weight slice) whose workgroups cover the scenes in order.  XCD x is given the x-th eighth of EVERY section: the same
+// scenes then meet the same L2 in every stage, so what a stage writes for a scene (x', pq, edges, edge_feat, A, feat)
+// is still in that L2 when the next stage reads it, instead of being fetched from another XCD's L2 / the Infinity
+// Cache.  Correctness never depends on the placement: this is only a permutation of the block index.
+#define GN_MAX_SECTIONS 32
+struct XcdSections {
+  int first[GN_MAX_SECTIONS + 1];   // prefix of logical workgroup indices, section by section
+  int n;
+  int enabled;
+};
+// physical block -> logical workgroup, or -1 for a padding block (the grid is 8 x the largest per-XCD share)
+__device__ __forceinline__ int gn_xcd_logical(const XcdSections& S, int p) {
+  if (!S.enabled) return p;
+  const int x = p & 7;
+  int slot = p >> 3;
+  for (int g = 0; g < S.n; ++g) {
+    const int W = S.first[g + 1] - S.first[g];
+    const int lo = (int)(((long long)W * x) >> 3), hi = (int)(((long long)W * (x + 1)) >> 3);
+    if (slot < hi - lo) return S.first[g] + lo + slot;
+    slot -= hi - lo;
+  }
+  return -1;
+}
+// host: finish a table whose first[0..n] is filled; returns the grid size
+static inline int gn_xcd_grid(XcdSections& S) {
+  static const bool off = getenv("GN_XCD") != nullptr && atoi(getenv("GN_XCD")) == 0;
+  const int total = S.first[S.n];
+  S.enabled = (!off && S.n <= GN_MAX_SECTIONS && total >= 64) ? 1 : 0;
+  if (!S.enabled) return total;
+  int worst = 0;
+  for (int x = 0; x < 8; ++x) {
+    int c = 0;
+    for (int g = 0; g < S.n; ++g) {
+      const int W = S.first[g + 1] - S.first[g];
+      c += (int)(((long long)W * (x + 1)) >> 3) - (int)(((long long)W * x) >> 3);
+    }
+    worst = c > worst ? c : worst;
+  }
+  return 8 * worst;
 }
 
 // Unordered pairs (i <= j) of N nodes, row-major over i: p(i,j) = i*N - i(i-1)/2 + (j - i).

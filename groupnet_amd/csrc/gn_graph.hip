@@ -273,9 +273,11 @@ __device__ __forceinline__ void node2edge_hyper_body(const WaveTable<gn_n2e_grou
     const float* xpb = s_xp + (size_t)s * N * GN_FEAT;
     // Q_e = sum_n H[e,n] * Qn_n      (lanes 32..63 hold channel c of Qn)
     float qe = 0.f;
+#pragma unroll 4
     for (int m = 0; m < cnt; ++m) qe = fmaf(s_h[m], pqb[s_idx[m] * LDP + lane], qe);
     const float qlo = __shfl(qe, 32 + c, GN_WAVE);  // both halves now see Q_e[c]
     // att for two members per step: half h takes member 2*t + h
+#pragma unroll 2
     for (int m0 = 0; m0 < cnt; m0 += 2) {
       const int m = m0 + h;
       const bool valid = m < cnt;
@@ -296,6 +298,7 @@ __device__ __forceinline__ void node2edge_hyper_body(const WaveTable<gn_n2e_grou
     sum += gn_nonmember_sum(N - cnt, mx);
     // edges[e] = sum_n (softmax_n * H[e,n]) * x'_n ; lane = feature
     float acc = 0.f;
+#pragma unroll 4
     for (int m = 0; m < cnt; ++m) {
       const float hv = s_h[m];
       const float wgt = expf(s_att[m] * hv - mx) / sum * hv;
@@ -415,8 +418,9 @@ struct PairTable {
 };
 template <typename TS>
 __global__ __launch_bounds__(kBlock) void node2edge_kernel(WaveTable<gn_n2e_group_t> T, PairTable pair, int B, int N,
-                                                           int SGh) {
-  const int wg = blockIdx.x;
+                                                           int SGh, XcdSections xs) {
+  const int wg = gn_uniform(gn_xcd_logical(xs, blockIdx.x));     // sections: the pairwise groups, then the hyper groups
+  if (wg < 0) return;
   const int n_pair_wgs = pair.first_wg[pair.n];
   if (wg < n_pair_wgs) {
     int g = 0;
@@ -942,9 +946,14 @@ static int node2edge_launch(const gn_n2e_group_t* groups, int n_groups, int B, i
   }
   T.first[T.n] = waves;
   const long long grid = pair_wgs + waves;
-  if (grid > 0x7fffffffLL) return GN_ERR_SHAPE;
+  if (grid > 0x3fffffffLL) return GN_ERR_SHAPE;
+  XcdSections xs{};
+  for (int g = 0; g < P.n; ++g) xs.first[xs.n++] = P.first_wg[g];
+  for (int g = 0; g < T.n; ++g) xs.first[xs.n++] = pair_wgs + (int)T.first[g];
+  xs.first[xs.n] = (int)grid;
+  // (pairwise workgroups are (scene chunk, band) with the band fastest: scene order, like every other stage)
   gn_allow_big_lds(node2edge_kernel<TS>);
-  hipLaunchKernelGGL(node2edge_kernel<TS>, dim3((unsigned)grid), dim3(kBlock), lds, s, T, P, B, N, SGh);
+  hipLaunchKernelGGL(node2edge_kernel<TS>, dim3((unsigned)gn_xcd_grid(xs)), dim3(kBlock), lds, s, T, P, B, N, SGh, xs);
   return gn_check_launch();
 }
 extern "C" int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, gn_stream_t stream) {

@@ -308,6 +308,7 @@ struct NodeTable {
   gn_node_group_t g[GN_MAX_GROUPS];
   int a_first[GN_MAX_GROUPS + 1];   // prefix of A workgroups per group, relative to chain_wgs
   int n, rows, wgs_per_group, chain_wgs;
+  XcdSections xs;                   // sections: every group's chain, then every (group, output-tile chunk) of WA
 };
 constexpr int kATiles = 8;   // output tiles of WA per A workgroup
 
@@ -317,7 +318,8 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
   __shared__ f32x4 wring[WS::kRingF4];
   const int wave = wave_id();
   const int lane = threadIdx.x & 63, h = lane >> 5;
-  const int wg = blockIdx.x;
+  const int wg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
+  if (wg < 0) return;
   WS ws;
   if (wg < Tb.chain_wgs) {
     const int gi = gn_uniform(wg / Tb.wgs_per_group);
@@ -411,13 +413,15 @@ __global__ __launch_bounds__(256, 2) void edge_x_kernel(GroupTable<gn_edge_group
                                                         const unsigned long long* __restrict__ offset_dev) {
   using WS = WStream<P>;
   __shared__ f32x4 wring[WS::kRingF4];
-  const int gi = find_group(Tb, blockIdx.x);
+  const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
+  if (lwg < 0) return;
+  const int gi = find_group(Tb, lwg);
   const gn_edge_group_t G = Tb.g[gi];
   const int rows = G.rows, K = G.K;
-  const int blk = (blockIdx.x - Tb.first_wg[gi]) * 4 + wave_id();
+  const int blk = (lwg - Tb.first_wg[gi]) * 4 + wave_id();
   const RowBlock rb = row_block(rows, blk);      // (a wave past the group's rows works on a clamped row, stores nothing)
   const int lane = rb.lane, h = rb.h;
-  const int unit = blockIdx.x * 4 + wave_id();
+  const int unit = lwg * 4 + wave_id();
   GN_STAMP(unit, 0);
   GN_STAMP(unit, 8);
   f32x16 in[2], z[2], lg;
@@ -537,12 +541,14 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
   constexpr int CH = WS::CH;
   __shared__ f32x4 wring[WS::kRingF4];
   __shared__ float part[4][32][64 + 8];   // wpr > 1: [wave][register 0..31][lane]; staged pair form: 2 x node rows
-  const int gi = find_group(Tb, blockIdx.x);
+  const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
+  if (lwg < 0) return;
+  const int gi = find_group(Tb, lwg);
   const gn_agg_group_t G = Tb.g[gi].a;
   const int wpr = Tb.g[gi].wpr;
   const int rows = G.rows, K = G.K;
   const int wave = wave_id();
-  const int wg = blockIdx.x - Tb.first_wg[gi];
+  const int wg = lwg - Tb.first_wg[gi];
   // wpr == 1: every wave owns a 32-row block and walks all K types; the workgroup's 4 waves share ONE weight stream
   //           through LDS (WStream);
   // wpr  > 1: wpr waves share one row block (groups with few row blocks: shorter critical path), wave `sub` of them
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
   const float* b1 = G.b1;
   const float* b2 = G.b2;
   WS ws;
-  const int unit = blockIdx.x * 4 + wave;
+  const int unit = lwg * 4 + wave;
   GN_STAMP(unit, 0);
   GN_STAMP(unit, 8);
 
@@ -828,17 +834,20 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
 
 // ---- A6 / closing MLP on the bf16 cores: y = W1 relu(W0 x + b0) + b1, dout <= 64 ---------------------------------
 // Image, hidden-tile-major: per hidden tile t the tiles [W0(t, in 0..IT-1), W1(0..OT-1, t)].  Input rows read from
-// x or formed on the fly (fused scatter, IT == 4) exactly as in mlp2_kernel.  blockIdx.y = group.
+// x or formed on the fly (fused scatter, IT == 4) exactly as in mlp2_kernel.
 template <int P, typename T, int IT, int HT, int OT>
 __global__ __launch_bounds__(256, IT == 4 ? 1 : 2) void mlp2_x_kernel(GroupTable<gn_mlp2_group_t> Tb, int rows, int dout, int ldy,
                                                         int N, float divisor) {
   using WS = WStream<P>;
   __shared__ f32x4 wring[WS::kRingF4];
-  const int blk = blockIdx.x * 4 + wave_id();
-  const gn_mlp2_group_t G = Tb.g[blockIdx.y];
+  const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
+  if (lwg < 0) return;
+  const int gi = find_group(Tb, lwg);             // (first_wg[g] = g * workgroups per group)
+  const int blk = (lwg - Tb.first_wg[gi]) * 4 + wave_id();
+  const gn_mlp2_group_t G = Tb.g[gi];
   const RowBlock rb = row_block(rows, blk);      // (a wave past the rows works on a clamped row, stores nothing)
   const int lane = rb.lane, h = rb.h;
-  const int unit = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave_id();
+  const int unit = lwg * 4 + wave_id();
   GN_STAMP(unit, 0);
   GN_STAMP(unit, 8);
   constexpr int kSub = HT * (2 * IT + 2 * OT);

@@ -113,7 +113,15 @@ struct GroupTable {
   G g[GN_MAX_GROUPS];
   int first_wg[GN_MAX_GROUPS + 1];
   int n;
+  XcdSections xs;     // bf16-core kernels: XCD-aware order of the logical workgroups (sections = groups)
 };
+// sections = the groups of a table; returns the grid size
+template <typename G>
+inline int table_xcd_grid(GroupTable<G>& T) {
+  T.xs.n = T.n;
+  for (int g = 0; g <= T.n; ++g) T.xs.first[g] = T.first_wg[g];
+  return gn_xcd_grid(T.xs);
+}
 template <typename G>
 __device__ __forceinline__ int find_group(const GroupTable<G>& t, int wg) {
   int g = 0;

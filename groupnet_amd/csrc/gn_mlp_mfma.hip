@@ -869,7 +869,11 @@ static int node_stage_launch(const gn_node_group_t* groups, int n_groups, int ro
     Tb.g[g] = G;
   }
   Tb.a_first[n_groups] = a_wgs;
-  hipLaunchKernelGGL((node_stage_kernel<P, T>), dim3(Tb.chain_wgs + a_wgs), dim3(256), 0, s, Tb);
+  // sections of equal size: every group's chain, then every (group, chunk) of WA
+  const int n_sec = (Tb.chain_wgs + a_wgs) / Tb.wgs_per_group;
+  Tb.xs.n = n_sec <= GN_MAX_SECTIONS ? n_sec : 1;
+  for (int i = 0; i <= Tb.xs.n; ++i) Tb.xs.first[i] = n_sec <= GN_MAX_SECTIONS ? i * Tb.wgs_per_group : i * (Tb.chain_wgs + a_wgs);
+  hipLaunchKernelGGL((node_stage_kernel<P, T>), dim3(gn_xcd_grid(Tb.xs)), dim3(256), 0, s, Tb);
   return gn_check_launch();
 }
 
@@ -928,9 +932,9 @@ static int edge_launch(const gn_edge_group_t* groups, int n_groups, float tau, u
   }
   T.first_wg[n_groups] = wg;
   if (twin)
-    hipLaunchKernelGGL((edge_x_kernel<1, __bf16>), dim3(wg), dim3(256), 0, stream, T, tau, seed, offset_dev);
+    hipLaunchKernelGGL((edge_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T, tau, seed, offset_dev);
   else if (xm)
-    hipLaunchKernelGGL((edge_x_kernel<3, float>), dim3(wg), dim3(256), 0, stream, T, tau, seed, offset_dev);
+    hipLaunchKernelGGL((edge_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T, tau, seed, offset_dev);
   else
     hipLaunchKernelGGL(edge_mlp_gumbel_kernel, dim3(wg), dim3(256), 0, stream, T, tau, seed, offset_dev);
   return gn_check_launch();
@@ -1011,9 +1015,9 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
   }
   T.first_wg[n_groups] = wg;
   if (twin)
-    hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(wg), dim3(256), 0, stream, T);
+    hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T);
   else if (xm)
-    hipLaunchKernelGGL((agg_x_kernel<3, float>), dim3(wg), dim3(256), 0, stream, T);
+    hipLaunchKernelGGL((agg_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T);
   else
     hipLaunchKernelGGL(agg_mlp_kernel, dim3(wg), dim3(256), 0, stream, T);
   return gn_check_launch();
@@ -1036,9 +1040,10 @@ extern "C" int gn_node_linear_f32(const float* x, const float* W, const float* b
 }
 
 template <int P, typename T>
-static int mlp2_x_launch(const GroupTable<gn_mlp2_group_t>& T_, int n_groups, int rows, int din, int dh, int dout, int ldy,
+static int mlp2_x_launch(GroupTable<gn_mlp2_group_t>& T_, int n_groups, int rows, int din, int dh, int dout, int ldy,
                          int N, float divisor, hipStream_t s) {
-  const dim3 grid(row_grid(rows), n_groups), block(256);
+  for (int g = 0; g <= n_groups; ++g) T_.first_wg[g] = g * row_grid(rows);
+  const dim3 grid(table_xcd_grid(T_)), block(256);
   const int OT = (dout + 31) / 32;
 #define GN_MLP2X(IT, HT, OTv) \
   hipLaunchKernelGGL((mlp2_x_kernel<P, T, IT, HT, OTv>), grid, block, 0, s, T_, rows, dout, ldy, N, divisor)
