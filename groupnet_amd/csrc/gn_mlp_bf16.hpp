@@ -73,6 +73,19 @@ __device__ __forceinline__ void make_parts(const f32x16& v, int hf, Parts<P>& x)
     }
   }
 }
+// P = 1 with the ReLU folded in: convert first (v_cvt_pk_bf16_f32, two values per instruction), then clamp the packed
+// bf16 pairs at zero as 16-bit integers (a negative float has its sign bit set, so max(x, 0) on the raw halves is
+// ReLU; -0 and negative NaNs become +0): 8 + 4 instructions per half tile instead of 8 v_max_f32 + 4 conversions —
+// the P = 1 kernels are bound by VALU issue, not by the matrix pipe.
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void make_parts_relu(const f32x16& v, int hf, Parts<1>& x) {
+  bf16x8 t;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) t[jj] = (__bf16)v[8 * hf + jj];
+  const i16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  x.p[0] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(i16x8, t), zero));
+}
+
 template <int P, int NT>
 __device__ __forceinline__ void make_parts_tiles(const f32x16 (&v)[NT], Parts<P> (&x)[NT][2]) {
 #pragma unroll
@@ -110,7 +123,7 @@ __device__ __forceinline__ void mfma_substep(const f32x4 (&w)[P], const Parts<P>
 // A stream is a sequence of segments (e.g. one per edge type) of `seg` sub-steps at `cur`, followed by `nxt`.
 template <int P>
 struct XStream {
-  static constexpr int D = P == 3 ? 4 : 16;   // ring depth in sub-steps
+  static constexpr int D = P == 3 ? 4 : 8;    // ring depth in sub-steps
   static constexpr int CH = 1;                // (positions are given in sub-steps: c0 is ignored)
   f32x4 q[D][P];
   const f32x4* cur;     // this lane's pointer at sub-step 0 of the current segment
@@ -156,71 +169,95 @@ struct WStream {
   static constexpr int R = 3;                    // chunks in the LDS ring
   static constexpr int PIECES = CH * P;          // 1-KiB pieces (64 lanes x 16 B) per chunk
   static constexpr int PW = PIECES / 4;          // pieces each of the 4 waves stages per chunk
-  static constexpr int kRingF4 = R * PIECES * 64;   // f32x4 elements of the ring (36 KiB / 24 KiB)
-  f32x4* ring;          // LDS ring, this lane's view
-  const f32x4* src;     // global image at this stream's first chunk, this lane's view
-  int last;             // local index of the image's last chunk (loads beyond it are clamped to it)
-  int wave;
+  static constexpr int kChunkF4 = PIECES * 64;   // f32x4 elements of a chunk
+  static constexpr int kRingF4 = R * kChunkF4;   // ... of the ring (36 KiB / 24 KiB)
+  static constexpr int QD = P == 3 ? 2 : 4;      // operand registers: sub-steps read ahead of their MFMA + 1.  A P = 3
+                                                 // sub-step is 192 cycles of matrix work — one ahead covers the LDS
+                                                 // latency; a P = 1 sub-step is 32 cycles, so three ahead
+  // Running state instead of index arithmetic per access (a P = 1 sub-step is ONE 32-cycle MFMA: a handful of
+  // address instructions per operand read would cost as much as the matrix work): the chunks are consumed strictly
+  // in order, so the ring slot of the current chunk, the wave's write position and its global read position advance
+  // by constants at every boundary; sub-step offsets inside a chunk are immediates of the ds_read.
+  const f32x4* rd_cur;    // LDS: current chunk, this lane's view
+  const f32x4* rd_next;   // LDS: next chunk
+  f32x4* wr;              // LDS: where this wave's pieces of chunk (current + 2) go
+  f32x4* ring0;           // LDS: slot 0, this lane's view
+  const f32x4* ld;        // global: this wave's pieces of the chunk loaded next
+  const f32x4* ld_last;   // ... of the image's last chunk (loads beyond it re-read that one)
+  int slot;               // ring slot of the current chunk
   f32x4 st[LOOK][PW];
-  f32x4 q[2][P];
+  f32x4 q[QD][P];
 
 #ifdef GN_DIAG_NO_BARRIER    // diagnostic builds only (results are wrong)
   __device__ __forceinline__ static void barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #else
   __device__ __forceinline__ static void barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
-  __device__ __forceinline__ const f32x4* piece_src(int chunk, int i) const {
-    return src + ((size_t)min(chunk, last) * PIECES + wave * PW + i) * 64;
-  }
-  __device__ __forceinline__ f32x4* piece_dst(int chunk, int i) const {
-    return ring + ((chunk % R) * PIECES + wave * PW + i) * 64;
-  }
-  __device__ __forceinline__ void read_ops(int chunk, int sub, int slot) {
-    const f32x4* p = ring + ((chunk % R) * PIECES + sub * P) * 64;
+  __device__ __forceinline__ void load_stage(int j) {
 #pragma unroll
-    for (int pp = 0; pp < P; ++pp) q[slot][pp] = p[pp * 64];
+    for (int i = 0; i < PW; ++i) st[j][i] = ld[i * 64];
+    ld = ld == ld_last ? ld : ld + kChunkF4;
+  }
+  // operands of sub-step `sub` (0 .. 2*CH-1: sub >= CH addresses the next chunk) into register set `set`
+  __device__ __forceinline__ void read_ops(int sub, int set) {
+    const f32x4* p = (sub < CH ? rd_cur : rd_next) + (sub % CH) * P * 64;
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) q[set][pp] = p[pp * 64];
   }
   // image: global address of the stream's first chunk; n_chunks: chunks from there to the end of the image
-  __device__ __forceinline__ void begin(const void* image, f32x4* lds_ring, int lane, int wave_, int n_chunks) {
-    ring = lds_ring + lane;
-    src = reinterpret_cast<const f32x4*>(image) + lane;
-    last = n_chunks - 1;
-    wave = wave_;
+  __device__ __forceinline__ void begin(const void* image, f32x4* lds_ring, int lane, int wave, int n_chunks) {
+    ring0 = lds_ring + lane;
+    ld = reinterpret_cast<const f32x4*>(image) + lane + wave * PW * 64;
+    ld_last = ld + (size_t)(n_chunks - 1) * kChunkF4;
+    f32x4* w0 = ring0 + wave * PW * 64;
+    // chunks 0 and 1 straight into slots 0 and 1, chunks 2 .. 2+LOOK-1 into the staging registers
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < 2; ++c) {
 #pragma unroll
-      for (int i = 0; i < PW; ++i) *piece_dst(c, i) = *piece_src(c, i);
+      for (int i = 0; i < PW; ++i) w0[c * kChunkF4 + i * 64] = ld[i * 64];
+      ld = ld == ld_last ? ld : ld + kChunkF4;
+    }
 #pragma unroll
-    for (int j = 0; j < LOOK; ++j)
-#pragma unroll
-      for (int i = 0; i < PW; ++i) st[j][i] = *piece_src(2 + j, i);
+    for (int j = 0; j < LOOK; ++j) load_stage(j);
+    slot = R - 1;                       // (the first boundary advances to slot 0)
+    rd_cur = ring0 + (R - 1) * kChunkF4;
+    rd_next = ring0;
+    wr = w0 + 2 * kChunkF4;             // chunk 2 -> slot 2
     barrier();
-    read_ops(0, 0, 0);
+    // operands of the first QD-1 sub-steps: "next chunk" is chunk 0 until the first boundary has run
+#pragma unroll
+    for (int j = 0; j + 1 < QD; ++j) read_ops(CH + j, j);
   }
-  // chunk boundary: `c` = local chunk index (runtime), `cl` = the same modulo LOOK (compile-time)
-  __device__ __forceinline__ void boundary(int c, int cl) {
+  // chunk boundary; `cl` = index of the chunk that starts here, modulo LOOK (compile-time)
+  __device__ __forceinline__ void boundary(int cl) {
     barrier();
+    slot = slot + 1 == R ? 0 : slot + 1;
+    rd_cur = rd_next;
+    rd_next = ring0 + (slot + 1 == R ? 0 : slot + 1) * kChunkF4;
 #pragma unroll
-    for (int i = 0; i < PW; ++i) *piece_dst(c + 2, i) = st[cl % LOOK][i];
-#pragma unroll
-    for (int i = 0; i < PW; ++i) st[cl % LOOK][i] = *piece_src(c + 2 + LOOK, i);
+    for (int i = 0; i < PW; ++i) wr[i * 64] = st[cl % LOOK][i];      // chunk + 2 -> the slot chunk - 1 occupied
+    wr = slot == 0 ? wr - 2 * kChunkF4 : wr + kChunkF4;               // slots of chunk+2: 2, 0, 1, 2, ... (R = 3)
+    load_stage(cl % LOOK);                                            // chunk + 2 + LOOK
   }
-  // acc += W[sub-step s of the segment that starts at local chunk c0] . x.  `s` is a compile-time constant at every
-  // call site; c0 may be a runtime value (a multiple of LOOK).  FENCE closes the scheduling region behind the step.
+  // acc += W[sub-step s of the current segment] . x.  `s` is a compile-time constant at every call site (segments
+  // start at chunk boundaries and are multiples of CH * LOOK sub-steps long where they repeat in a runtime loop);
+  // the first argument is unused (XStream has the same interface).  FENCE closes the scheduling region behind the step.
   template <bool FENCE = true>
-  __device__ __forceinline__ void step(int c0, int s, const Parts<P>& x, f32x16& acc) {
-    const int c = c0 + s / CH;
-    if (s % CH == 0) boundary(c, s / CH);
-    read_ops(c0 + (s + 1) / CH, (s + 1) % CH, (s + 1) & 1);      // next sub-step's operands (LDS latency under the MFMAs)
-    mfma_substep<P>(q[s & 1], x, acc);
+  __device__ __forceinline__ void step(int, int s, const Parts<P>& x, f32x16& acc) {
+    if (s % CH == 0) boundary(s / CH);
+    // operands of the sub-step QD-1 ahead (LDS latency under the MFMAs); chunk c+1 is visible throughout chunk c
+    read_ops(s % CH + QD - 1, (s + QD - 1) % QD);
+    mfma_substep<P>(q[s % QD], x, acc);
     if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
   }
   // pass over sub-steps [s, s + n) without using them: the wave still takes part in every chunk boundary among them
-  __device__ __forceinline__ void skip(int c0, int s, int n) {
+  __device__ __forceinline__ void skip(int, int s, int n) {
 #pragma unroll
     for (int p = s; p < s + n; ++p)
-      if (p % CH == 0) boundary(c0 + p / CH, p / CH);
-    read_ops(c0 + (s + n) / CH, (s + n) % CH, (s + n) & 1);
+      if (p % CH == 0) boundary(p / CH);
+    const int basec = (s + n - 1) / CH;          // the chunk the last boundary made current
+#pragma unroll
+    for (int j = 0; j + 1 < QD; ++j) read_ops(s + n + j - basec * CH, (s + n + j) % QD);
   }
 };
 
@@ -236,7 +273,9 @@ struct WStream {
 // (vmcnt counts in order).
 //   c0, s0: the segment's first chunk (runtime) and the sub-step of A0 inside it (compile-time);
 //   hid0: bias tile 0 (loaded early by the caller).
-template <int P, int IT, int OT, int HT, typename Stream, typename PostFn>
+//   PACKED_RELU (P = 1 only): the hidden layer's ReLU is applied on the packed bf16 operands (make_parts_relu);
+//   `post` then must not apply it.
+template <int P, int IT, int OT, int HT, bool PACKED_RELU = false, typename Stream, typename PostFn>
 __device__ __forceinline__ void layer_pair(Stream& ws, int c0, int s0, const Parts<P> (&xi)[IT][2],
                                            const f32x16& hid0, const float* __restrict__ b0, int h,
                                            f32x16 (&out)[OT], PostFn post) {
@@ -264,8 +303,13 @@ __device__ __forceinline__ void layer_pair(Stream& ws, int c0, int s0, const Par
     }
     post(t, cur);
     Parts<P> xh[2];
-    make_parts<P>(cur, 0, xh[0]);
-    make_parts<P>(cur, 1, xh[1]);
+    if constexpr (PACKED_RELU) {
+      make_parts_relu(cur, 0, xh[0]);
+      make_parts_relu(cur, 1, xh[1]);
+    } else {
+      make_parts<P>(cur, 0, xh[0]);
+      make_parts<P>(cur, 1, xh[1]);
+    }
     if (t + 1 < HT) {
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
@@ -345,9 +389,11 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
     GN_STAMP(unit, 1);
     // image: the 64->256->64 pair in pipeline order (A_t = [W0(t,in0), W0(t,in1)], B_t = [W1(0,t), W1(1,t)]), then
     // [Wpq(0,in0), Wpq(0,in1), Wpq(1,in0), Wpq(1,in1)]
-    layer_pair<P, 2, 2, 8>(ws, 0, 0, xi, hid0, b0, h, xp, [&](int t, f32x16& hid) {
-      relu16(hid);
-      if (G.hid_out != nullptr && rb.live) store_tile(G.hid_out + (size_t)rb.row * 256 + 32 * t + 4 * h, hid);
+    layer_pair<P, 2, 2, 8, P == 1>(ws, 0, 0, xi, hid0, b0, h, xp, [&](int t, f32x16& hid) {
+      if constexpr (P == 3) {
+        relu16(hid);
+        if (G.hid_out != nullptr && rb.live) store_tile(G.hid_out + (size_t)rb.row * 256 + 32 * t + 4 * h, hid);
+      }
     });
     GN_STAMP(unit, 2);
     store_rows<2>(reinterpret_cast<T*>(G.xp), GN_FEAT, rb.row, h, rb.live, xp);
@@ -457,17 +503,21 @@ __global__ __launch_bounds__(256, 2) void edge_x_kernel(GroupTable<gn_edge_group
   make_parts_tiles<P, 2>(in, xi);
   GN_STAMP(unit, 1);
   // ---- pair A: 64 -> 128 -> 64, 4 hidden tiles x (4 + 4) sub-steps, pipeline order ----
-  layer_pair<P, 2, 2, 4>(ws, 0, 0, xi, hidA0, bi0, h, z, [&](int t, f32x16& hid) {
-    relu16(hid);
-    if (G.keep_z1 != nullptr && rb.live) store_tile(G.keep_z1 + (size_t)rb.row * 128 + 32 * t + 4 * h, hid);
+  layer_pair<P, 2, 2, 4, P == 1>(ws, 0, 0, xi, hidA0, bi0, h, z, [&](int t, f32x16& hid) {
+    if constexpr (P == 3) {
+      relu16(hid);
+      if (G.keep_z1 != nullptr && rb.live) store_tile(G.keep_z1 + (size_t)rb.row * 128 + 32 * t + 4 * h, hid);
+    }
   });
   GN_STAMP(unit, 2);
   if (G.keep_z != nullptr) store_rows<2>(G.keep_z, GN_FEAT, rb.row, h, rb.live, z);
   make_parts_tiles<P, 2>(z, xi);
   // ---- pair B: 64 -> 256 -> (logits | factor), 8 hidden tiles x (4 + 2) sub-steps, pipeline order ----
-  layer_pair<P, 2, 1, 8>(ws, 0, 32, xi, hidB0, bd0, h, lgv, [&](int t, f32x16& hid) {
-    relu16(hid);
-    if (G.keep_dh1 != nullptr && rb.live) store_tile(G.keep_dh1 + (size_t)rb.row * 256 + 32 * t + 4 * h, hid);
+  layer_pair<P, 2, 1, 8, P == 1>(ws, 0, 32, xi, hidB0, bd0, h, lgv, [&](int t, f32x16& hid) {
+    if constexpr (P == 3) {
+      relu16(hid);
+      if (G.keep_dh1 != nullptr && rb.live) store_tile(G.keep_dh1 + (size_t)rb.row * 256 + 32 * t + 4 * h, hid);
+    }
   });
   lg = lgv[0];
   GN_STAMP(unit, 3);
@@ -765,9 +815,23 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
       const int kc = k + 1 < K ? k + 1 : k;
       const float efk_next = efrow[kc];
       const f32x16 hid0_next = load_bias_tile(b1 + kc * 128, h);
-      add_b2(b2 + k * 64, efk, lane, h, out);
-      layer_pair<P, 2, 2, 4>(ws, k * 32 / CH, 0, xi, hid0, b1 + k * 128, h, out,
-                             [&](int, f32x16& hid) { relu_scale16(hid, efk); });
+      if constexpr (P == 1) {
+        // VALU-lean form: the type's layer 2 accumulates into a temporary that starts at b2_k, ReLU runs on the
+        // packed bf16 operands, and feat += ef_k * (W2k relu(..) + b2k) is 32 FMAs per type — instead of scaling every
+        // hidden value (64 multiplications) and two extra fp32 MFMAs for the bias
+        f32x16 tmp[2];
+        tmp[0] = load_bias_tile(b2 + k * 64, h);
+        tmp[1] = load_bias_tile(b2 + k * 64 + 32, h);
+        layer_pair<P, 2, 2, 4, true>(ws, k * 32 / CH, 0, xi, hid0, b1 + k * 128, h, tmp, [&](int, f32x16&) {});
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[o][r] = fmaf(efk, tmp[o][r], out[o][r]);
+      } else {
+        add_b2(b2 + k * 64, efk, lane, h, out);
+        layer_pair<P, 2, 2, 4>(ws, k * 32 / CH, 0, xi, hid0, b1 + k * 128, h, out,
+                               [&](int, f32x16& hid) { relu_scale16(hid, efk); });
+      }
       hid0 = hid0_next;
       efk = efk_next;
     }
@@ -791,8 +855,19 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
       const float efk = efrow[k];
       const f32x16 hid0_next = load_bias_tile(b1 + kc * 128, h);
       xs.segment(Wx + (size_t)k * 32 * P * 64, Wx + (size_t)kc * 32 * P * 64, 32);
-      add_b2(b2 + k * 64, efk, lane, h, out);
-      layer_pair<P, 2, 2, 4>(xs, 0, 0, xi, hid0, b1 + k * 128, h, out, [&](int, f32x16& hid) { relu_scale16(hid, efk); });
+      if constexpr (P == 1) {
+        f32x16 tmp[2];
+        tmp[0] = load_bias_tile(b2 + k * 64, h);
+        tmp[1] = load_bias_tile(b2 + k * 64 + 32, h);
+        layer_pair<P, 2, 2, 4, true>(xs, 0, 0, xi, hid0, b1 + k * 128, h, tmp, [&](int, f32x16&) {});
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[o][r] = fmaf(efk, tmp[o][r], out[o][r]);
+      } else {
+        add_b2(b2 + k * 64, efk, lane, h, out);
+        layer_pair<P, 2, 2, 4>(xs, 0, 0, xi, hid0, b1 + k * 128, h, out, [&](int, f32x16& hid) { relu_scale16(hid, efk); });
+      }
       hid0 = hid0_next;
     }
   }
@@ -870,9 +945,11 @@ __global__ __launch_bounds__(256, IT == 4 ? 1 : 2) void mlp2_x_kernel(GroupTable
     make_parts_tiles<P, IT>(in, xi);
   }
   GN_STAMP(unit, 1);
-  layer_pair<P, IT, OT, HT>(ws, 0, 0, xi, hid0, b0, h, out, [&](int t, f32x16& hid) {
-    relu16(hid);
-    if (G.hid_out != nullptr && rb.live) store_tile(G.hid_out + (size_t)rb.row * (32 * HT) + 32 * t + 4 * h, hid);
+  layer_pair<P, IT, OT, HT, P == 1>(ws, 0, 0, xi, hid0, b0, h, out, [&](int t, f32x16& hid) {
+    if constexpr (P == 3) {
+      relu16(hid);
+      if (G.hid_out != nullptr && rb.live) store_tile(G.hid_out + (size_t)rb.row * (32 * HT) + 32 * t + 4 * h, hid);
+    }
   });
   GN_STAMP(unit, 2);
   if (rb.live) {

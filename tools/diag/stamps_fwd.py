@@ -11,11 +11,14 @@ from groupnet_amd.multiscale import MultiScaleHGNN
 import groupnet_amd as G
 import groupnet_amd.MS_HGNN_batch as M
 
-B, N = 512, 11
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 11
+SC = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [2, 5, 11]
+DT = torch.bfloat16 if (len(sys.argv) > 5 and sys.argv[5] == "bf16") else torch.float32
 dev = torch.device("cuda")
 torch.manual_seed(0)
-blk = MultiScaleHGNN([2, 5, 11]).to(dev).eval()
-f = torch.randn(B, N, 64, device=dev)
+blk = MultiScaleHGNN(SC).to(dev).eval()
+f = torch.randn(B, N, 64, device=dev).to(DT)
 lib = _lib.load()
 lib.gn_debug_read_stamps.restype = ctypes.c_int
 lib.gn_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
@@ -51,12 +54,12 @@ def wrap(name, n_units_fn, groups_fn=None):
         return r
     setattr(ops, name, w)
 
-wrap("node_stage_grouped", lambda items, keep, specs: 704 + 528, lambda *a: [("chain", slice(0, 704)), ("A", slice(704, 1232))])
+wrap("node_stage_grouped", lambda items, keep, specs: 8192 if B > 512 else 704 + 528, (lambda *a: None) if B > 512 else (lambda *a: [("chain", slice(0, 704)), ("A", slice(704, 1232))]))
 def edge_units(items, *a, **k):
     return sum(((it[0].shape[0] * it[0].shape[1] + 127) // 128) * 4 for it in items)
-wrap("edge_mlp_gumbel_grouped", edge_units, lambda items, *a, **k: [("pair", slice(0, 1056)), ("hyper", slice(1056, 1056 + 400))])
-wrap("agg_mlp_grouped", lambda items: 4 * 700, None)
-wrap("mlp2_grouped", lambda items, keep=None: 4 * 44 * 4, None)
+wrap("edge_mlp_gumbel_grouped", (lambda *a, **k: 8192) if B > 512 else edge_units, (lambda *a, **k: None) if B > 512 else (lambda items, *a, **k: [("pair", slice(0, 1056)), ("hyper", slice(1056, 1056 + 400))]))
+wrap("agg_mlp_grouped", lambda items: 8192 if B > 512 else 4 * 700, None)
+wrap("mlp2_grouped", lambda items, keep=None: 8192 if B > 512 else 4 * 44 * 4, None)
 M.ops = ops
 with torch.no_grad():
     G.set_noise_mode("device", seed=3)
