@@ -18,7 +18,23 @@ import re
 import sys
 
 
+def demangle(name):
+    if not name.startswith("_Z"):
+        return name
+    import shutil, subprocess
+    tool = shutil.which("llvm-cxxfilt") or shutil.which("c++filt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    try:
+        out = subprocess.run([tool, name], capture_output=True, text=True, check=True).stdout.strip()
+        if out and not out.startswith("_Z"):
+            return out
+        raise ValueError(name)
+    except Exception:
+        m = re.search(r"\d+([a-z][a-z0-9_]*_kernel)", name)
+        return m.group(1) if m else name
+
+
 def short(name):
+    name = demangle(name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     return re.sub(r"[<(].*$", "", name)

@@ -8,7 +8,26 @@ import re
 import sys
 
 
+def demangle(name: str) -> str:
+    if not name.startswith("_Z"):
+        return name
+    import shutil, subprocess
+    tool = shutil.which("llvm-cxxfilt") or shutil.which("c++filt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    try:
+        out = subprocess.run([tool, name], capture_output=True, text=True, check=True).stdout.strip()
+        if out and not out.startswith("_Z"):
+            return out
+        raise ValueError(name)
+    except Exception:
+        m = re.search(r"\d+([a-z][a-z0-9_]*_kernel)I(.*?)E+v", name)      # e.g. bf16 template arguments llvm-cxxfilt does not know
+        if m:
+            args = m.group(2).replace("Li1EDF16b", "1, __bf16").replace("Li2EDF16b", "2, __bf16").replace("DF16b", "__bf16")
+            return f"{m.group(1)}<{args}>"
+        return name
+
+
 def short(name: str) -> str:
+    name = demangle(name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"\(.*$", "", name)
     name = re.sub(r"^void ", "", name)
