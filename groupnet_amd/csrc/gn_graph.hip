@@ -569,6 +569,7 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const TS* __
       const TS* f4 = feat + (size_t)b * E * GN_FEAT + 4 * d;
       if (MODE == 2) {
         // every pair {n,j} once: the pair row already holds both ordered edges (and the self-loop's 2)
+#pragma unroll 8
         for (int j = 0; j < N; ++j) {
           const f32x4 v = ld4(f4 + (size_t)gn_pair_index(n, j, N) * GN_FEAT);
           acc[0] += v[0];
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const TS* __
         }
       } else if (MODE == 1) {
         // (n,n) counts twice (H = 2 on self-loops); fp32 tolerance makes the edge order immaterial
+#pragma unroll 4
         for (int j = 0; j < N; ++j) {
           const f32x4 v = ld4(f4 + (size_t)(n * N + j) * GN_FEAT);
           const f32x4 w = ld4(f4 + (size_t)(j * N + n) * GN_FEAT);

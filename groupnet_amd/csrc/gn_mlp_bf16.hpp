@@ -50,6 +50,16 @@ struct Parts {
   bf16x8 p[P];
 };
 
+// eight fp32 registers -> four packed bf16 pairs.  Written as ONE vector conversion so that it lowers to four
+// two-source v_cvt_pk_bf16_f32; element-by-element casts lower to eight one-source conversions plus four v_perm.
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 cvt_half(const f32x16& v, int hf) {
+  f32x8 h;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) h[jj] = v[8 * hf + jj];
+  return __builtin_convertvector(h, bf16x8);
+}
+
 // bf16 operand(s) of half `hf` of a 32-feature fp32 tile held in a lane's 16 registers
 template <int P>
 __device__ __forceinline__ void make_parts(const f32x16& v, int hf, Parts<P>& x) {
@@ -68,22 +78,29 @@ __device__ __forceinline__ void make_parts(const f32x16& v, int hf, Parts<P>& x)
       x.p[0][jj] = a;
       x.p[1][jj] = b;
       x.p[2][jj] = c;
-    } else {
-      x.p[0][jj] = (__bf16)v[8 * hf + jj];
     }
   }
+  if constexpr (P == 1) x.p[0] = cvt_half(v, hf);
 }
 // P = 1 with the ReLU folded in: convert first (v_cvt_pk_bf16_f32, two values per instruction), then clamp the packed
 // bf16 pairs at zero as 16-bit integers (a negative float has its sign bit set, so max(x, 0) on the raw halves is
-// ReLU; -0 and negative NaNs become +0): 8 + 4 instructions per half tile instead of 8 v_max_f32 + 4 conversions —
-// the P = 1 kernels are bound by VALU issue, not by the matrix pipe.
-typedef short i16x8 __attribute__((ext_vector_type(8)));
+// ReLU; -0 and negative NaNs become +0): 4 + 4 instructions per half tile instead of 8 v_max_f32 + 4 conversions —
+// the P = 1 kernels are bound by VALU issue, not by the matrix pipe.  Written pair by pair: clamping the whole
+// 8-vector as i16x8 makes the compiler scalarise the conversion (8 one-source conversions + 4 v_perm per half).
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void make_parts_relu(const f32x16& v, int hf, Parts<1>& x) {
-  bf16x8 t;
+  u32x4 r;
 #pragma unroll
-  for (int jj = 0; jj < 8; ++jj) t[jj] = (__bf16)v[8 * hf + jj];
-  const i16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  x.p[0] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(i16x8, t), zero));
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 pr = {v[8 * hf + 2 * j], v[8 * hf + 2 * j + 1]};
+    const i16x2 zero = {0, 0};
+    r[j] = __builtin_bit_cast(unsigned,
+                              __builtin_elementwise_max(__builtin_bit_cast(i16x2, __builtin_convertvector(pr, bf16x2)), zero));
+  }
+  x.p[0] = __builtin_bit_cast(bf16x8, r);
 }
 
 template <int P, int NT>
@@ -188,10 +205,18 @@ struct WStream {
   f32x4 st[LOOK][PW];
   f32x4 q[QD][P];
 
+  // Two barriers.  begin(): the first chunks were just written, so the wave drains its LDS queue before it signals.
+  // boundary(): NO drain — the operand reads already in flight (QD-1 sub-steps ahead) stay in flight across the
+  // barrier.  That is safe because LDS operations of a wave complete in order: (1) the pieces this wave wrote at the
+  // previous boundary are older than operand reads it has since waited for, so they have landed before it signals;
+  // (2) the slot overwritten after the barrier held chunk c-1, whose last operand reads every wave consumed (waited
+  // for) before its last MFMA of that chunk, i.e. before it arrived here.
 #ifdef GN_DIAG_NO_BARRIER    // diagnostic builds only (results are wrong)
-  __device__ __forceinline__ static void barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+  __device__ __forceinline__ static void barrier_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+  __device__ __forceinline__ static void barrier() { asm volatile("" ::: "memory"); }
 #else
-  __device__ __forceinline__ static void barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  __device__ __forceinline__ static void barrier_drain() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  __device__ __forceinline__ static void barrier() { asm volatile("s_barrier" ::: "memory"); }
 #endif
   __device__ __forceinline__ void load_stage(int j) {
 #pragma unroll
@@ -223,7 +248,7 @@ struct WStream {
     rd_cur = ring0 + (R - 1) * kChunkF4;
     rd_next = ring0;
     wr = w0 + 2 * kChunkF4;             // chunk 2 -> slot 2
-    barrier();
+    barrier_drain();
     // operands of the first QD-1 sub-steps: "next chunk" is chunk 0 until the first boundary has run
 #pragma unroll
     for (int j = 0; j + 1 < QD; ++j) read_ops(CH + j, j);

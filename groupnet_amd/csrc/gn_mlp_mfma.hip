@@ -1014,8 +1014,13 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
     wg += ((T.g[g].a.rows + 31) / 32 * T.g[g].wpr + 3) / 4;
   }
   T.first_wg[n_groups] = wg;
-  if (twin)
-    hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T);
+  if (twin) {
+    static const int pad = getenv("GN_DIAG_AGG_PAD_LDS") ? atoi(getenv("GN_DIAG_AGG_PAD_LDS")) : 0;   // diagnostic: occupancy
+    if (pad > 0)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(agg_x_kernel<1, __bf16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+    hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), pad, stream, T);
+  }
   else if (xm)
     hipLaunchKernelGGL((agg_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T);
   else

@@ -58,7 +58,7 @@ wrap("node_stage_grouped", lambda items, keep, specs: 8192 if B > 512 else 704 +
 def edge_units(items, *a, **k):
     return sum(((it[0].shape[0] * it[0].shape[1] + 127) // 128) * 4 for it in items)
 wrap("edge_mlp_gumbel_grouped", (lambda *a, **k: 8192) if B > 512 else edge_units, (lambda *a, **k: None) if B > 512 else (lambda items, *a, **k: [("pair", slice(0, 1056)), ("hyper", slice(1056, 1056 + 400))]))
-wrap("agg_mlp_grouped", lambda items: 8192 if B > 512 else 4 * 700, None)
+wrap("agg_mlp_grouped", lambda items: 8192 if B > 512 else 4 * 700, (lambda items: None) if B > 512 else (lambda items: [("hyperA", slice(0, 352)), ("hyperB", slice(352, 704)), ("pair", slice(704, 1760)), ("small", slice(1760, 1824))]))
 wrap("mlp2_grouped", lambda items, keep=None: 8192 if B > 512 else 4 * 44 * 4, None)
 M.ops = ops
 with torch.no_grad():
