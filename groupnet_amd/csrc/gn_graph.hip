@@ -214,17 +214,33 @@ __device__ __forceinline__ int find_wave_group(const WaveTable<G>& t, long long 
 // A3 second half: attention-weighted node -> edge pooling
 // --------------------------------------------------------------------------------------------
 // Hyper modules.  A workgroup stages the x' and pq rows of SG scenes of ONE module in LDS (pq rows padded to 65
-// floats) and its 4 waves walk those scenes' hyperedges, one wave per hyperedge at a time: the members of the edge
-// (nodes with H != 0) are compacted with a ballot; non-members enter the softmax only as exp(0 - max) terms, exactly
-// as softmax(att * H) treats them (MS_HGNN_batch.py:135-137,366-368); every per-member access then is an LDS read
-// (the first version read the members' rows straight from L2: three dependent global loads per member and wave —
-// 305 us at N = 50, B = 1024).  `first` counts workgroups.
+// floats) and walks those scenes' hyperedges in bands of EB.  Per band, five thread-parallel phases (a barrier
+// between them), every one with a THREAD per output element instead of a wave per hyperedge — the wave-per-edge form
+// spent ~800 wave instructions per hyperedge on wave-uniform work (the softmax weight of every member evaluated by
+// all 64 lanes, a 5-step shuffle reduction per member) and took 237 us at N = 50, B = 1024:
+//   P0  member lists: the nodes with H != 0 of each edge, compacted with a ballot (one wave per edge; non-members
+//       enter the softmax only as exp(0 - max) terms, exactly as softmax(att * H) treats them,
+//       MS_HGNN_batch.py:135-137,366-368);
+//   P1  Q_e[c] = sum_m H[e,m] Qn_m[c]                                   thread = (edge, channel)
+//   P2  v[e,m] = H[e,m] (b2 + sum_c w2[c] relu(P_m[c] + Q_e[c]))        thread = (edge, member), w2 in SGPRs
+//   P3  softmax over all N nodes, weight[e,m] = softmax * H[e,m]        half-wave = edge
+//   P4  edges[e] = sum_m weight[e,m] x'_m                               thread = (edge, 4 features)
+// `first` counts workgroups.
+__device__ __forceinline__ float gn_half_max(float v) {
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, GN_WAVE));
+  return v;
+}
+__host__ __device__ inline size_t n2e_hyper_scratch_floats(int EB, int N) {
+  return (size_t)3 * EB * N + (size_t)EB * 33 + (size_t)3 * EB + 8;
+}
 template <typename TS>
-__device__ __forceinline__ void node2edge_hyper_body(const WaveTable<gn_n2e_group_t>& T, int B, int N, int SG, int wg) {
+__device__ __forceinline__ void node2edge_hyper_body(const WaveTable<gn_n2e_group_t>& T, int B, int N, int SG, int EB,
+                                                     int wg) {
   extern __shared__ __align__(16) float lds[];
-  constexpr int LDP = GN_FEAT + 1;
+  constexpr int LDP = GN_FEAT + 1, LDQ = 33;
   const int wave = gn_uniform((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63;
   const int gi = gn_uniform(find_wave_group(T, wg));
   const gn_n2e_group_t G = T.g[gi];
   const int E = G.E;
@@ -232,10 +248,31 @@ __device__ __forceinline__ void node2edge_hyper_body(const WaveTable<gn_n2e_grou
   const int sg = min(SG, B - b0);
   float* s_xp = lds;                                   // sg x N x 64
   float* s_pq = s_xp + (size_t)SG * N * GN_FEAT;       // sg x N x 65
-  float* base = s_pq + (size_t)SG * N * LDP + (size_t)wave * 3 * N;   // per wave: idx[N] (int), hval[N], att[N]
-  int* s_idx = reinterpret_cast<int*>(base);
-  float* s_h = base + N;
-  float* s_att = base + 2 * N;
+  float* sc = s_pq + (size_t)SG * N * LDP;             // band scratch
+  int* s_idx = reinterpret_cast<int*>(sc);             // EB x N   member -> node
+  float* s_h = sc + (size_t)EB * N;                    // EB x N   H[e, member]
+  float* s_v = s_h + (size_t)EB * N;                   // EB x N   att * H, then softmax weight * H
+  float* s_Q = s_v + (size_t)EB * N;                   // EB x 33
+  int* s_cnt = reinterpret_cast<int*>(s_Q + (size_t)EB * LDQ);   // EB
+  int* s_wmax = s_cnt + EB;                            // 4: the waves' largest member counts
+  float w2r[32];                                        // (uniform addresses: scalar loads, the values stay in SGPRs)
+#pragma unroll
+  for (int c = 0; c < 32; ++c) w2r[c] = G.w2[c];
+  const float b2v = *G.b2;
+  const int total = sg * E;
+  // H rows ride one band ahead in registers (N <= 64: one value per lane and edge, up to U edges per wave and band):
+  // a wave that loaded each row when it needed it paid one memory latency per hyperedge.
+  constexpr int U = 4;
+  const bool pre = N <= 64 && EB <= U * (kBlock / 64);
+  float hn[U];
+  auto fetch = [&](int e0n) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int le = wave + u * (kBlock / 64);
+      hn[u] = (pre && le < EB && e0n + le < total && lane < N) ? G.H[((size_t)b0 * E + e0n + le) * N + lane] : 0.f;
+    }
+  };
+  fetch(0);
   {
     const TS* src = reinterpret_cast<const TS*>(G.xp) + (size_t)b0 * N * GN_FEAT;
     f32x4* dst = reinterpret_cast<f32x4*>(s_xp);
@@ -250,62 +287,109 @@ __device__ __forceinline__ void node2edge_hyper_body(const WaveTable<gn_n2e_grou
       d[3] = v[3];
     }
   }
-  __syncthreads();
-  const float w2c = G.w2[c];
-  const float b2v = *G.b2;
-  for (int eidx = wave; eidx < sg * E; eidx += kBlock / 64) {
-    const int s = eidx / E, e = eidx - s * E;
-    int cnt = 0;
-    const float* Hrow = G.H + ((size_t)(b0 + s) * E + e) * N;
-    for (int n0 = 0; n0 < N; n0 += 64) {
-      const int n = n0 + lane;
-      const float hv = n < N ? Hrow[n] : 0.f;
-      const unsigned long long mask = __ballot(hv != 0.f);
-      if (hv != 0.f) {
-        const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-        s_idx[pos] = n;
-        s_h[pos] = hv;
+  for (int e0 = 0; e0 < total; e0 += EB) {
+    const int eb = min(EB, total - e0);
+    __syncthreads();            // the staged rows are visible / the previous band's scratch is free
+    // ---- P0: member lists ----
+    int wmax = 0;
+    if (pre) {
+      float hc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) hc[u] = hn[u];
+      fetch(e0 + EB);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int le = wave + u * (kBlock / 64);
+        if (le < eb) {
+          const float hv = hc[u];
+          const unsigned long long mask = __ballot(hv != 0.f);
+          if (hv != 0.f) {
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            s_idx[le * N + pos] = lane;
+            s_h[le * N + pos] = hv;
+          }
+          const int cnt = __popcll(mask);
+          if (lane == 0) s_cnt[le] = cnt;
+          wmax = max(wmax, cnt);
+        }
       }
-      cnt += __popcll(mask);
+    } else {
+      for (int le = wave; le < eb; le += kBlock / 64) {
+        const float* Hrow = G.H + ((size_t)b0 * E + e0 + le) * N;
+        int cnt = 0;
+        for (int n0 = 0; n0 < N; n0 += 64) {
+          const int n = n0 + lane;
+          const float hv = n < N ? Hrow[n] : 0.f;
+          const unsigned long long mask = __ballot(hv != 0.f);
+          if (hv != 0.f) {
+            const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            s_idx[le * N + pos] = n;
+            s_h[le * N + pos] = hv;
+          }
+          cnt += __popcll(mask);
+        }
+        if (lane == 0) s_cnt[le] = cnt;
+        wmax = max(wmax, cnt);
+      }
     }
-    __builtin_amdgcn_wave_barrier();
-    const float* pqb = s_pq + (size_t)s * N * LDP;
-    const float* xpb = s_xp + (size_t)s * N * GN_FEAT;
-    // Q_e = sum_n H[e,n] * Qn_n      (lanes 32..63 hold channel c of Qn)
-    float qe = 0.f;
+    if (lane == 0) s_wmax[wave] = wmax;
+    __syncthreads();
+    const int kmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    // ---- P1: Q_e ----
+    for (int it = threadIdx.x; it < eb * 32; it += kBlock) {
+      const int le = it >> 5, c = it & 31;
+      const float* pqb = s_pq + (size_t)((e0 + le) / E) * N * LDP + 32 + c;
+      const int cnt = s_cnt[le];
+      float q = 0.f;
 #pragma unroll 4
-    for (int m = 0; m < cnt; ++m) qe = fmaf(s_h[m], pqb[s_idx[m] * LDP + lane], qe);
-    const float qlo = __shfl(qe, 32 + c, GN_WAVE);  // both halves now see Q_e[c]
-    // att for two members per step: half h takes member 2*t + h
-#pragma unroll 2
-    for (int m0 = 0; m0 < cnt; m0 += 2) {
-      const int m = m0 + h;
-      const bool valid = m < cnt;
-      const int n = valid ? s_idx[m] : 0;
-      const float p = pqb[n * LDP + c];
-      float t = valid ? w2c * fmaxf(p + qlo, 0.f) : 0.f;
-      t = gn_half_sum(t);
-      if (valid && c == 0) s_att[m] = t + b2v;
+      for (int m = 0; m < cnt; ++m) q = fmaf(s_h[le * N + m], pqb[s_idx[le * N + m] * LDP], q);
+      s_Q[le * LDQ + c] = q;
     }
-    __builtin_amdgcn_wave_barrier();
-    // softmax over all N nodes of v_n = att_n * H[e,n]  (0 for non-members)
-    float mx = cnt < N ? 0.f : -INFINITY;
-    for (int m = lane; m < cnt; m += 64) mx = fmaxf(mx, s_att[m] * s_h[m]);
-    mx = gn_wave_max(mx);
-    float sum = 0.f;
-    for (int m = lane; m < cnt; m += 64) sum += expf(s_att[m] * s_h[m] - mx);
-    sum = gn_wave_sum(sum);
-    sum += gn_nonmember_sum(N - cnt, mx);
-    // edges[e] = sum_n (softmax_n * H[e,n]) * x'_n ; lane = feature
-    float acc = 0.f;
+    __syncthreads();
+    // ---- P2: attention logits times H ----
+    for (int it = threadIdx.x; it < eb * kmax; it += kBlock) {
+      const int le = it / kmax, m = it - le * kmax;
+      if (m < s_cnt[le]) {
+        const float* p = s_pq + ((size_t)((e0 + le) / E) * N + s_idx[le * N + m]) * LDP;
+        const float* Qe = s_Q + le * LDQ;
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) t = fmaf(w2r[c], fmaxf(p[c] + Qe[c], 0.f), t);
+        s_v[le * N + m] = (t + b2v) * s_h[le * N + m];
+      }
+    }
+    __syncthreads();
+    // ---- P3: softmax over all N nodes of v_n = att_n * H[e,n] (0 for non-members); weight = softmax * H ----
+    for (int le = threadIdx.x >> 5; le < eb; le += kBlock / 32) {
+      const int c = threadIdx.x & 31;
+      const int cnt = s_cnt[le];
+      float mx = cnt < N ? 0.f : -INFINITY;
+      for (int m = c; m < cnt; m += 32) mx = fmaxf(mx, s_v[le * N + m]);
+      mx = gn_half_max(mx);
+      float sum = 0.f;
+      for (int m = c; m < cnt; m += 32) sum += expf(s_v[le * N + m] - mx);
+      sum = gn_half_sum(sum);
+      sum += gn_nonmember_sum(N - cnt, mx);
+      for (int m = c; m < cnt; m += 32) s_v[le * N + m] = expf(s_v[le * N + m] - mx) / sum * s_h[le * N + m];
+    }
+    __syncthreads();
+    // ---- P4: edges[e] = sum_m weight_m x'_m ----
+    for (int it = threadIdx.x; it < eb * 16; it += kBlock) {
+      const int le = it >> 4, f4 = it & 15;
+      const f32x4* xpb = reinterpret_cast<const f32x4*>(s_xp + (size_t)((e0 + le) / E) * N * GN_FEAT) + f4;
+      const int cnt = s_cnt[le];
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int m = 0; m < cnt; ++m) {
-      const float hv = s_h[m];
-      const float wgt = expf(s_att[m] * hv - mx) / sum * hv;
-      acc = fmaf(wgt, xpb[s_idx[m] * GN_FEAT + lane], acc);
+      for (int m = 0; m < cnt; ++m) {
+        const float w = s_v[le * N + m];
+        const f32x4 x = xpb[s_idx[le * N + m] * (GN_FEAT / 4)];
+        acc[0] = fmaf(w, x[0], acc[0]);
+        acc[1] = fmaf(w, x[1], acc[1]);
+        acc[2] = fmaf(w, x[2], acc[2]);
+        acc[3] = fmaf(w, x[3], acc[3]);
+      }
+      st4(reinterpret_cast<TS*>(G.edges) + ((size_t)b0 * E + e0 + le) * GN_FEAT + 4 * f4, acc);
     }
-    st1(reinterpret_cast<TS*>(G.edges) + ((size_t)(b0 + s) * E + e) * GN_FEAT + lane, acc);
-    __builtin_amdgcn_wave_barrier();     // (the wave's scratch is rewritten by its next hyperedge)
   }
 }
 
@@ -418,7 +502,7 @@ struct PairTable {
 };
 template <typename TS>
 __global__ __launch_bounds__(kBlock) void node2edge_kernel(WaveTable<gn_n2e_group_t> T, PairTable pair, int B, int N,
-                                                           int SGh, XcdSections xs) {
+                                                           int SGh, int EBh, XcdSections xs) {
   const int wg = gn_uniform(gn_xcd_logical(xs, blockIdx.x));     // sections: the pairwise groups, then the hyper groups
   if (wg < 0) return;
   const int n_pair_wgs = pair.first_wg[pair.n];
@@ -427,7 +511,7 @@ __global__ __launch_bounds__(kBlock) void node2edge_kernel(WaveTable<gn_n2e_grou
     while (g + 1 < pair.n && wg >= pair.first_wg[g + 1]) ++g;
     node2edge_pairwise_body<TS>(pair.g[g], B, N, pair.SG[g], pair.bands[g], wg - pair.first_wg[g]);
   } else {
-    node2edge_hyper_body<TS>(T, B, N, SGh, wg - n_pair_wgs);
+    node2edge_hyper_body<TS>(T, B, N, SGh, EBh, wg - n_pair_wgs);
   }
 }
 
@@ -932,13 +1016,21 @@ static int node2edge_launch(const gn_n2e_group_t* groups, int n_groups, int B, i
   }
   P.first_wg[P.n] = pair_wgs;
   // hyper groups: scenes per workgroup so that the staged rows stay <= 32 KiB while the grid keeps >= ~1024 workgroups
-  int SGh = 1;
+  int SGh = 1, EBh = 1;
   if (T.n > 0) {
     const size_t per_scene = (size_t)N * (GN_FEAT + GN_FEAT + 1) * sizeof(float);
-    const size_t scratch = (size_t)(kBlock / 64) * 3 * N * sizeof(float);
-    if (per_scene + scratch > 158 * 1024) return GN_ERR_LDS;
     while (SGh < 8 && (size_t)(2 * SGh) * per_scene <= 32 * 1024 && (long long)((B + 2 * SGh - 1) / (2 * SGh)) * T.n >= 1024)
       SGh *= 2;
+    // hyperedges per band: ~12 KiB of member lists (3 words per (edge, node) slot), at least 4 edges, at most the
+    // most edges any group's workgroup walks
+    int maxE = 1;
+    for (int g = 0; g < T.n; ++g) maxE = maxE > T.g[g].E ? maxE : T.g[g].E;
+    EBh = (int)(12288 / ((size_t)12 * N + 144));
+    EBh = EBh < 4 ? 4 : EBh;
+    if (N <= 64 && EBh > 16) EBh = 16;        // (the band whose H rows a workgroup can hold in registers, see the kernel)
+    EBh = EBh > SGh * maxE ? SGh * maxE : EBh;
+    const size_t scratch = n2e_hyper_scratch_floats(EBh, N) * sizeof(float);
+    if ((size_t)SGh * per_scene + scratch > 158 * 1024) return GN_ERR_LDS;
     const size_t l = (size_t)SGh * per_scene + scratch;
     lds = lds > l ? lds : l;
     for (int g = 0; g < T.n; ++g) {
@@ -955,7 +1047,7 @@ static int node2edge_launch(const gn_n2e_group_t* groups, int n_groups, int B, i
   xs.first[xs.n] = (int)grid;
   // (pairwise workgroups are (scene chunk, band) with the band fastest: scene order, like every other stage)
   gn_allow_big_lds(node2edge_kernel<TS>);
-  hipLaunchKernelGGL(node2edge_kernel<TS>, dim3((unsigned)gn_xcd_grid(xs)), dim3(kBlock), lds, s, T, P, B, N, SGh, xs);
+  hipLaunchKernelGGL(node2edge_kernel<TS>, dim3((unsigned)gn_xcd_grid(xs)), dim3(kBlock), lds, s, T, P, B, N, SGh, EBh, xs);
   return gn_check_launch();
 }
 extern "C" int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, gn_stream_t stream) {

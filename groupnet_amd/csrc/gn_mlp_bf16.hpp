@@ -40,7 +40,7 @@ extern "C" int gn_debug_read_stamps(void* dst, size_t bytes) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gn_stamp_buf), bytes);
 }
 #else
-#define GN_STAMP(unit, slot) do {} while (0)
+#define GN_STAMP(unit, slot) do { (void)(unit); } while (0)
 #endif
 
 namespace {
