@@ -43,6 +43,13 @@ extern "C" int gn_debug_read_stamps(void* dst, size_t bytes) {
 #define GN_STAMP(unit, slot) do { (void)(unit); } while (0)
 #endif
 
+// workgroups per CU the bf16-storage (P = 1) edge / aggregation kernels are compiled for
+#ifndef GN_OCC_P1
+#define GN_OCC_P1 2
+#endif
+
+#include <type_traits>
+
 namespace {
 
 template <int P>
@@ -275,6 +282,16 @@ struct WStream {
     mfma_substep<P>(q[s % QD], x, acc);
     if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
   }
+  // the same sub-step against RB row blocks: ONE operand read feeds RB MFMAs (x_of(b), acc_of(b): block b's operand
+  // and accumulator)
+  template <int RB, bool FENCE = true, typename XF, typename AF>
+  __device__ __forceinline__ void step_rb(int s, XF x_of, AF acc_of) {
+    if (s % CH == 0) boundary(s / CH);
+    read_ops(s % CH + QD - 1, (s + QD - 1) % QD);
+#pragma unroll
+    for (int b = 0; b < RB; ++b) mfma_substep<P>(q[s % QD], x_of(b), acc_of(b));
+    if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
+  }
   // pass over sub-steps [s, s + n) without using them: the wave still takes part in every chunk boundary among them
   __device__ __forceinline__ void skip(int, int s, int n) {
 #pragma unroll
@@ -479,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
 // Image (80 sub-steps), hidden-tile-major: per hidden tile t of init_MLP the tiles [Wi0(t,in0), Wi0(t,in1),
 // Wi1(0,t), Wi1(1,t)], then per hidden tile t of [Wd0] the tiles [Wd0(t,in0), Wd0(t,in1), Wd1(0,t)].
 template <int P, typename T>
-__global__ __launch_bounds__(256, 2) void edge_x_kernel(GroupTable<gn_edge_group_t> Tb, float tau,
+__global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void edge_x_kernel(GroupTable<gn_edge_group_t> Tb, float tau,
                                                         unsigned long long seed,
                                                         const unsigned long long* __restrict__ offset_dev) {
   using WS = WStream<P>;
@@ -610,12 +627,16 @@ __device__ __forceinline__ void add_b2(const float* __restrict__ b2k, float efk,
   out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1, efb, out[1], 0, 0, 0);
 }
 
+constexpr int kAggPartBytes = 4 * 32 * (64 + 8) * 4;
 template <int P, typename T>
-__global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) {
+__global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(GroupTable<AggGroup> Tb) {
   using WS = WStream<P>;
   constexpr int CH = WS::CH;
   __shared__ f32x4 wring[WS::kRingF4];
-  __shared__ float part[4][32][64 + 8];   // wpr > 1: [wave][register 0..31][lane]; staged pair form: 2 x node rows
+  // wpr > 1: [wave][register 0..31][lane]; staged pair form: 2 x node rows.  Dynamic: a launch whose groups all run one
+  // wave per row block without the stage (the large bf16 configurations) passes 0 bytes and fits more workgroups per CU.
+  extern __shared__ __align__(16) float part_dyn[];
+  float (*part)[32][64 + 8] = reinterpret_cast<float (*)[32][64 + 8]>(part_dyn);
   const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
   if (lwg < 0) return;
   const int gi = find_group(Tb, lwg);
@@ -930,6 +951,146 @@ __global__ __launch_bounds__(256, 2) void agg_x_kernel(GroupTable<AggGroup> Tb) 
   }
   GN_STAMP(unit, 4);
   GN_STAMP(unit, 9);
+}
+
+// ---- A5 typed MLP, bf16 storage, TWO row blocks per wave (large launches, one wave per row-block pair) --------------
+// A P = 1 sub-step is ONE 32-cycle MFMA against one 1-KiB weight operand: with one row block per wave the LDS operand
+// read, the chunk boundary (barrier, staged writes) and the scalar bookkeeping are paid per MFMA and the matrix pipe
+// idles for more than half of the time (tools/microbench/substep_rate.hip: 52 % at two workgroups per CU).  Here
+// every operand read feeds two MFMAs (the same weights against rows [64w, 64w+32) and [64w+32, 64w+64)): 82 % in the
+// same microbenchmark at two workgroups per CU — which is why the kernel must fit 256 registers:
+//   * no per-type temporary: feat += W2k (relu(W1k eo + b1k) ef_k) with ef_k >= 0 applied BEFORE the packed ReLU, and
+//     the b2 term  sum_k ef_k b2k  as fp32 MFMAs (32x32x2: two types per instruction) ahead of the stream;
+//   * bias tiles form one sequence over all types (b1 is [K][128]): two tiles ahead, no per-type restart.
+// Stream order per type as everywhere (A0 A1 B0 A2 B1 A3 B2 B3, 8 sub-steps = one chunk per pair); V_t (scale,
+// convert, ReLU of hidden tile t) runs in the shadow of the MFMA group that precedes B_t: A_{t+1}, or B_2 for t = 3.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void agg_rb2_kernel(GroupTable<AggGroup> Tb) {
+  constexpr int RB = 2;
+  using WS = WStream<1>;
+  __shared__ f32x4 wring[WS::kRingF4];
+  const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
+  if (lwg < 0) return;
+  const int gi = find_group(Tb, lwg);
+  const gn_agg_group_t G = Tb.g[gi].a;
+  const int rows = G.rows, K = G.K;
+  const int wave = wave_id();
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int blk0 = ((lwg - Tb.first_wg[gi]) * 4 + wave) * RB;
+  RowBlock rb[RB];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) rb[b] = row_block(rows, blk0 + b);   // (a block past the rows: clamped loads, no stores)
+  WS ws;
+  ws.begin(G.W12x, wring, lane, wave, K * 32 / WS::CH);
+  Parts<1> xi[RB][2][2];
+  const float* efrow[RB];
+  f32x16 out[RB][2];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) {
+    f32x16 in[2];
+    if (G.eo != nullptr)
+      load_rows<2>(reinterpret_cast<const T*>(G.eo), GN_FEAT, rb[b].row_ld, h, in);
+    else
+      gather_rows<T>(G, rb[b].row_ld, h, in);
+    make_parts_tiles<1, 2>(in, xi[b]);
+    efrow[b] = G.edge_feat + (size_t)rb[b].row_ld * K;
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[b][o][r] = 0.f;
+  }
+  // sum_k ef_k b2k: lane (i, hh) of the A operand carries b2[k + hh][32 o + i], lane (j, hh) of B ef[row j][k + hh]
+  if (G.b2 != nullptr) {
+#pragma unroll 1
+    for (int k = 0; k < K; k += 2) {
+      const int kk = k + h;
+      const bool on = kk < K;
+      const float a0 = on ? G.b2[kk * 64 + (lane & 31)] : 0.f;
+      const float a1 = on ? G.b2[kk * 64 + 32 + (lane & 31)] : 0.f;
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        const float e = on ? efrow[b][kk] : 0.f;
+        out[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, e, out[b][0], 0, 0, 0);
+        out[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, e, out[b][1], 0, 0, 0);
+      }
+    }
+  }
+  const float* b1 = G.b1;
+  const int last_tile = 4 * K - 1;
+  f32x16 bias_n = load_bias_tile(b1, h);                         // tile 0 of type 0
+  f32x16 bias_nn = load_bias_tile(b1 + 32 * min(1, last_tile), h);
+  float ef[RB];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) ef[b] = efrow[b][0];
+  f32x16 hidn[RB];
+  // A_t: hidden tile t of the current type, all row blocks (positions inside the type, compile-time)
+  auto A = [&](auto fence, int s0, int next_bias_tile) {
+#pragma unroll
+    for (int b = 0; b < RB; ++b) hidn[b] = bias_n;
+    bias_n = bias_nn;
+    bias_nn = load_bias_tile(b1 + 32 * min(next_bias_tile, last_tile), h);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      ws.template step_rb<RB, decltype(fence)::value>(
+          s0 + u, [&](int b) -> const Parts<1>& { return xi[b][u >> 1][u & 1]; }, [&](int b) -> f32x16& { return hidn[b]; });
+  };
+  auto Bm = [&](auto fence, int s0, const Parts<1> (&xh)[RB][2]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)                       // [W2(0,t) hf0, hf1, W2(1,t) hf0, hf1]
+      ws.template step_rb<RB, decltype(fence)::value>(
+          s0 + u, [&](int b) -> const Parts<1>& { return xh[b][u & 1]; }, [&](int b) -> f32x16& { return out[b][u >> 1]; });
+  };
+  auto V = [&](Parts<1> (&xh)[RB][2]) {               // consumes hidn
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      f32x16 cur = hidn[b];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cur[r] *= ef[b];
+      make_parts_relu(cur, 0, xh[b][0]);
+      make_parts_relu(cur, 1, xh[b][1]);
+    }
+  };
+  auto shadow = [&]() {                               // 4 sub-steps x RB MFMAs with V's VALU spread between them
+#pragma unroll
+    for (int i = 0; i < 4 * RB; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+      if (i % RB == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using Fence = std::integral_constant<bool, true>;
+  using NoFence = std::integral_constant<bool, false>;
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    const int kn = k + 1 < K ? k + 1 : k;
+    float efn[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) efn[b] = efrow[b][kn];
+    const int t0 = 4 * k;
+    Parts<1> xa[RB][2], xb[RB][2];
+    A(Fence{}, 0, t0 + 2);                // A0 (bias tiles t0+2 .. ride two ahead)
+    V(xa);                                // V0 in the shadow of A1
+    A(NoFence{}, 4, t0 + 3);
+    shadow();
+    Bm(Fence{}, 8, xa);                   // B0
+    V(xb);                                // V1 | A2
+    A(NoFence{}, 12, t0 + 4);
+    shadow();
+    Bm(Fence{}, 16, xb);                  // B1
+    V(xa);                                // V2 | A3
+    A(NoFence{}, 20, t0 + 5);
+    shadow();
+    V(xb);                                // V3 | B2
+    Bm(NoFence{}, 24, xa);
+    shadow();
+    Bm(Fence{}, 28, xb);                  // B3
+#pragma unroll
+    for (int b = 0; b < RB; ++b) ef[b] = efn[b];
+  }
+  T* feat = reinterpret_cast<T*>(G.feat);
+#pragma unroll
+  for (int b = 0; b < RB; ++b) store_rows<2>(feat, GN_FEAT, rb[b].row, h, rb[b].live, out[b]);
 }
 
 // ---- A6 / closing MLP on the bf16 cores: y = W1 relu(W0 x + b0) + b1, dout <= 64 ---------------------------------

@@ -1014,15 +1014,32 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
     wg += ((T.g[g].a.rows + 31) / 32 * T.g[g].wpr + 3) / 4;
   }
   T.first_wg[n_groups] = wg;
+  // bf16 storage, a large launch: two row blocks per wave (agg_rb2_kernel)
   if (twin) {
-    static const int pad = getenv("GN_DIAG_AGG_PAD_LDS") ? atoi(getenv("GN_DIAG_AGG_PAD_LDS")) : 0;   // diagnostic: occupancy
-    if (pad > 0)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(agg_x_kernel<1, __bf16>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-    hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), pad, stream, T);
+    // (pairs of row blocks must still fill the chip: >= 2048 waves in all.  GN_AGG_RB2 = 0 / 1 forces the choice —
+    // the parity tests run small cases through both kernels)
+    long long pairs = 0;
+    for (int g = 0; g < n_groups; ++g) pairs += ((groups[g].rows + 31) / 32 + 1) / 2;
+    bool rb2 = pairs >= 2048;
+    if (const char* e = getenv("GN_AGG_RB2")) rb2 = atoi(e) != 0;
+    if (rb2) {
+      wg = 0;
+      for (int g = 0; g < n_groups; ++g) {
+        T.first_wg[g] = wg;
+        wg += ((T.g[g].a.rows + 31) / 32 + 7) / 8;
+      }
+      T.first_wg[n_groups] = wg;
+      hipLaunchKernelGGL((agg_rb2_kernel<__bf16>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T);
+      return gn_check_launch();
+    }
   }
+  bool need_part = false;       // LDS for partial sums (wpr > 1) or the staged node rows
+  for (int g = 0; g < n_groups; ++g) need_part = need_part || T.g[g].wpr > 1 || T.g[g].stage != 0;
+  const size_t part_bytes = need_part ? kAggPartBytes : 0;
+  if (twin)
+    hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
   else if (xm)
-    hipLaunchKernelGGL((agg_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T);
+    hipLaunchKernelGGL((agg_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
   else
     hipLaunchKernelGGL(agg_mlp_kernel, dim3(wg), dim3(256), 0, stream, T);
   return gn_check_launch();
