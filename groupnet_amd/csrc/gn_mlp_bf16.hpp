@@ -186,10 +186,11 @@ struct XStream {
 //                 chunk c+2+LOOK : global -> staging registers
 // Requirements: all 4 waves of the workgroup call begin / step / skip with identical arguments (no early exits);
 // segment lengths are multiples of CH * LOOK sub-steps wherever the chunk index is not a compile-time constant.
-template <int P>
+template <int P, int LOOK_ = (P == 3 ? 2 : 4)>
 struct WStream {
   static constexpr int CH = P == 3 ? 4 : 8;      // sub-steps per chunk
-  static constexpr int LOOK = P == 3 ? 2 : 4;    // chunks between a piece's global load and its LDS write
+  static constexpr int LOOK = LOOK_;             // chunks between a piece's global load and its LDS write (the kernels
+                                                 // with two row blocks per wave spend twice as long per chunk: 2)
   static constexpr int R = 3;                    // chunks in the LDS ring
   static constexpr int PIECES = CH * P;          // 1-KiB pieces (64 lanes x 16 B) per chunk
   static constexpr int PW = PIECES / 4;          // pieces each of the 4 waves stages per chunk
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
 template <typename T>
 __global__ __launch_bounds__(256, 2) void agg_rb2_kernel(GroupTable<AggGroup> Tb) {
   constexpr int RB = 2;
-  using WS = WStream<1>;
+  using WS = WStream<1, 2>;
   __shared__ f32x4 wring[WS::kRingF4];
   const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
   if (lwg < 0) return;
@@ -1091,6 +1092,227 @@ __global__ __launch_bounds__(256, 2) void agg_rb2_kernel(GroupTable<AggGroup> Tb
   T* feat = reinterpret_cast<T*>(G.feat);
 #pragma unroll
   for (int b = 0; b < RB; ++b) store_rows<2>(feat, GN_FEAT, rb[b].row, h, rb[b].live, out[b]);
+}
+
+// ---- A4 on bf16 storage, two row blocks per wave (large launches) — see agg_rb2_kernel for the why -----------------
+// Same image and stream order as edge_x_kernel<1>: pair A (64 -> 128 -> 64: z), pair B (64 -> 256 -> logits | factor),
+// then the Gumbel-softmax epilogue per row block.  The bias tiles of both pairs ride ONE two-ahead pipeline (the last
+// two loads of pair A fetch the first two tiles of pair B).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void edge_rb2_kernel(GroupTable<gn_edge_group_t> Tb, float tau, unsigned long long seed,
+                                                          const unsigned long long* __restrict__ offset_dev) {
+  constexpr int RB = 2;
+  using WS = WStream<1, 2>;
+  __shared__ f32x4 wring[WS::kRingF4];
+  const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
+  if (lwg < 0) return;
+  const int gi = find_group(Tb, lwg);
+  const gn_edge_group_t G = Tb.g[gi];
+  const int rows = G.rows, K = G.K;
+  const int wave = wave_id();
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int blk0 = ((lwg - Tb.first_wg[gi]) * 4 + wave) * RB;
+  RowBlock rb[RB];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) rb[b] = row_block(rows, blk0 + b);
+  const float* bi0 = G.bias;
+  const float* bi1 = G.bias + 128;
+  const float* bd0 = G.bias + 192;
+  const float* bd1 = G.bias + 448;
+  WS ws;
+  ws.begin(G.Wx, wring, lane, wave, 80 / WS::CH);
+  Parts<1> xi[RB][2][2];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) {
+    f32x16 in[2];
+    load_rows<2>(reinterpret_cast<const T*>(G.edges), GN_FEAT, rb[b].row_ld, h, in);
+    make_parts_tiles<1, 2>(in, xi[b]);
+  }
+  f32x16 bias_n = load_bias_tile(bi0, h), bias_nn = load_bias_tile(bi0 + 32, h);
+  f32x16 hidn[RB];
+  // A: one hidden tile for all row blocks at stream position s0; nb: the bias tile loaded for two tiles later
+  auto A = [&](auto fence, int s0, const float* nb) {
+#pragma unroll
+    for (int b = 0; b < RB; ++b) hidn[b] = bias_n;
+    bias_n = bias_nn;
+    bias_nn = load_bias_tile(nb, h);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      ws.template step_rb<RB, decltype(fence)::value>(
+          s0 + u, [&](int b) -> const Parts<1>& { return xi[b][u >> 1][u & 1]; }, [&](int b) -> f32x16& { return hidn[b]; });
+  };
+  auto V = [&](Parts<1> (&xh)[RB][2]) {               // consumes hidn
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      make_parts_relu(hidn[b], 0, xh[b][0]);
+      make_parts_relu(hidn[b], 1, xh[b][1]);
+    }
+  };
+  using Fence = std::integral_constant<bool, true>;
+  using NoFence = std::integral_constant<bool, false>;
+  // ---- pair A: 64 -> 128 -> 64 (positions 0 .. 31) ----
+  {
+    f32x16 z[RB][2];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      z[b][0] = load_bias_tile(bi1, h);
+      z[b][1] = load_bias_tile(bi1 + 32, h);
+    }
+    auto Bm = [&](auto fence, int s0, const Parts<1> (&xh)[RB][2]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        ws.template step_rb<RB, decltype(fence)::value>(
+            s0 + u, [&](int b) -> const Parts<1>& { return xh[b][u & 1]; }, [&](int b) -> f32x16& { return z[b][u >> 1]; });
+    };
+    auto shadow = [&]() {
+#pragma unroll
+      for (int i = 0; i < 4 * RB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        if (i % RB == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    Parts<1> xa[RB][2], xb[RB][2];
+    A(Fence{}, 0, bi0 + 64);
+    V(xa);
+    A(NoFence{}, 4, bi0 + 96);
+    shadow();
+    Bm(Fence{}, 8, xa);
+    V(xb);
+    A(NoFence{}, 12, bd0);               // (bias tiles 0, 1 of pair B)
+    shadow();
+    Bm(Fence{}, 16, xb);
+    V(xa);
+    A(NoFence{}, 20, bd0 + 32);
+    shadow();
+    V(xb);
+    Bm(NoFence{}, 24, xa);
+    shadow();
+    Bm(Fence{}, 28, xb);
+#pragma unroll
+    for (int b = 0; b < RB; ++b) make_parts_tiles<1, 2>(z[b], xi[b]);
+  }
+  // ---- pair B: 64 -> 256 -> (logits | factor) (positions 32 .. 79: A_t 4 sub-steps, B_t 2) ----
+  f32x16 lg[RB];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) lg[b] = load_bias_tile(bd1, h);
+  {
+    auto Bm = [&](auto fence, int s0, const Parts<1> (&xh)[RB][2]) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        ws.template step_rb<RB, decltype(fence)::value>(
+            s0 + u, [&](int b) -> const Parts<1>& { return xh[b][u & 1]; }, [&](int b) -> f32x16& { return lg[b]; });
+    };
+    auto shadowA = [&]() {
+#pragma unroll
+      for (int i = 0; i < 4 * RB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        if (i % RB == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto shadowB = [&]() {
+#pragma unroll
+      for (int i = 0; i < 2 * RB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+        if (i % RB == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    Parts<1> xa[RB][2], xb[RB][2];
+    auto tile_ptr = [&](int t) { return bd0 + 32 * (t < 7 ? t : 7); };
+    A(Fence{}, 32, tile_ptr(2));          // A0
+    V(xa);
+    A(NoFence{}, 36, tile_ptr(3));        // V0 | A1
+    shadowA();
+    Bm(Fence{}, 40, xa);                  // B0
+    V(xb);
+    A(NoFence{}, 42, tile_ptr(4));        // V1 | A2
+    shadowA();
+    Bm(Fence{}, 46, xb);                  // B1
+    V(xa);
+    A(NoFence{}, 48, tile_ptr(5));        // V2 | A3
+    shadowA();
+    Bm(Fence{}, 52, xa);                  // B2
+    V(xb);
+    A(NoFence{}, 54, tile_ptr(6));        // V3 | A4
+    shadowA();
+    Bm(Fence{}, 58, xb);                  // B3
+    V(xa);
+    A(NoFence{}, 60, tile_ptr(7));        // V4 | A5
+    shadowA();
+    Bm(Fence{}, 64, xa);                  // B4
+    V(xb);
+    A(NoFence{}, 66, tile_ptr(7));        // V5 | A6
+    shadowA();
+    Bm(Fence{}, 70, xb);                  // B5
+    V(xa);
+    A(NoFence{}, 72, tile_ptr(7));        // V6 | A7
+    shadowA();
+    V(xb);                                // V7 | B6
+    Bm(NoFence{}, 76, xa);
+    shadowB();
+    Bm(Fence{}, 78, xb);                  // B7
+  }
+  // ---- epilogue, one row block after the other (as edge_x_kernel) ----
+  const unsigned long long pbase = G.philox_offset + (offset_dev ? *offset_dev : 0ull);
+  auto epilogue = [&](const RowBlock& r, const f32x16& lgb) {
+    long long o1 = r.row_ld, o2 = r.row_ld;
+    bool diag = true;
+    if (G.sym_N > 0) {
+      const int N = G.sym_N, Pn = gn_pair_count(N);
+      const int bb = r.row_ld / Pn, p = r.row_ld - bb * Pn;
+      int i, j;
+      gn_pair_decode(p, N, i, j);
+      o1 = (long long)bb * N * N + i * N + j;
+      o2 = (long long)bb * N * N + j * N + i;
+      diag = i == j;
+    }
+    float u1[8], u2[8];
+    fetch_uniforms(G.U, pbase, seed, o1, K, h, u1);
+    if (G.sym_N > 0) fetch_uniforms(G.U, pbase, seed, o2, K, h, u2);
+    float facv = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (feat_of(q, h) == K) facv = lgb[q];
+    facv += __shfl_xor(facv, 32, GN_WAVE);
+    const float sig = 1.f / (1.f + expf(-facv));
+    float d1[8], d2[8];
+    gumbel_softmax_row(lgb, u1, K, tau, h, d1);
+    if (G.sym_N > 0) gumbel_softmax_row(lgb, u2, K, tau, h, d2);
+    if (r.live) {
+      float* frow = G.edge_feat + (size_t)r.row * K;
+      T* dist = reinterpret_cast<T*>(G.dist);
+      if (G.sym_N == 0) {
+        T* drow = dist + (size_t)r.row * K;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int f = feat_of(q, h);
+          if (f < K) {
+            st1(drow + f, d1[q]);
+            frow[f] = sig * d1[q];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int f = feat_of(q, h);
+          if (f < K) {
+            if (dist != nullptr) {
+              st1(dist + (size_t)o1 * K + f, d1[q]);
+              if (!diag) st1(dist + (size_t)o2 * K + f, d2[q]);
+            }
+            frow[f] = diag ? 2.f * (sig * d1[q]) : sig * d1[q] + sig * d2[q];
+          }
+        }
+      }
+    }
+  };
+  epilogue(rb[0], lg[0]);
+  epilogue(rb[1], lg[1]);
 }
 
 // ---- A6 / closing MLP on the bf16 cores: y = W1 relu(W0 x + b0) + b1, dout <= 64 ---------------------------------

@@ -931,8 +931,24 @@ static int edge_launch(const gn_edge_group_t* groups, int n_groups, float tau, u
     wg += row_grid(G.rows);
   }
   T.first_wg[n_groups] = wg;
-  if (twin)
+  if (twin) {
+    // a large launch: two row blocks per wave (edge_rb2_kernel); GN_EDGE_RB2 = 0 / 1 forces the choice (parity tests)
+    long long pairs = 0;
+    for (int g = 0; g < n_groups; ++g) pairs += ((groups[g].rows + 31) / 32 + 1) / 2;
+    bool rb2 = pairs >= 2048;
+    if (const char* e = getenv("GN_EDGE_RB2")) rb2 = atoi(e) != 0;
+    if (rb2) {
+      wg = 0;
+      for (int g = 0; g < n_groups; ++g) {
+        T.first_wg[g] = wg;
+        wg += ((groups[g].rows + 31) / 32 + 7) / 8;
+      }
+      T.first_wg[n_groups] = wg;
+      hipLaunchKernelGGL((edge_rb2_kernel<__bf16>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T, tau, seed, offset_dev);
+      return gn_check_launch();
+    }
     hipLaunchKernelGGL((edge_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T, tau, seed, offset_dev);
+  }
   else if (xm)
     hipLaunchKernelGGL((edge_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T, tau, seed, offset_dev);
   else

@@ -62,10 +62,11 @@ def safe_rows(corr, scale):
 def test_bf16_block_matches_fp32_oracle(B, N, scales, rb2, monkeypatch):
     """The whole multiscale block on bf16 storage vs the fp32 oracle (decomposed attention) on the same
     bf16-rounded agent features and the same uniforms.  N=50 / scales {2,4,8,16} is BASELINE config 4's shape;
-    rb2 forces the typed aggregation MLP through its one-row-block ("0") or two-row-blocks-per-wave ("1") kernel
+    rb2 forces the edge MLP and the typed aggregation MLP through their one-row-block ("0") or two-row-blocks-per-wave ("1") kernels
     (the launcher picks the latter by itself only at sizes the oracle cannot reach; B=3: ragged last block pair)."""
     if rb2 is not None:
         monkeypatch.setenv("GN_AGG_RB2", rb2)
+        monkeypatch.setenv("GN_EDGE_RB2", rb2)
     blk, sp, shs = block_and_states(scales, seed=11)
     h = torch.randn(B, N, 64).bfloat16()
     noise = [[torch.rand(s)] for s in blk.noise_shapes(B, N)]
