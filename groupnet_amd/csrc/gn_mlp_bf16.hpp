@@ -578,8 +578,8 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void edge_x_kernel(Gro
   facv += __shfl_xor(facv, 32, GN_WAVE);   // exactly one of the two lanes holds it, the other has 0
   const float sig = 1.f / (1.f + expf(-facv));
   float d1[8], d2[8];
-  gumbel_softmax_row(lg, u1, K, tau, h, d1);
-  if (G.sym_N > 0) gumbel_softmax_row(lg, u2, K, tau, h, d2);
+  gumbel_softmax_row<P == 1>(lg, u1, K, tau, h, d1);
+  if (G.sym_N > 0) gumbel_softmax_row<P == 1>(lg, u2, K, tau, h, d2);
   if (rb.live) {
     float* frow = G.edge_feat + (size_t)rb.row * K;
     T* dist = reinterpret_cast<T*>(G.dist);
@@ -1281,8 +1281,8 @@ __global__ __launch_bounds__(256, 2) void edge_rb2_kernel(GroupTable<gn_edge_gro
     facv += __shfl_xor(facv, 32, GN_WAVE);
     const float sig = 1.f / (1.f + expf(-facv));
     float d1[8], d2[8];
-    gumbel_softmax_row(lgb, u1, K, tau, h, d1);
-    if (G.sym_N > 0) gumbel_softmax_row(lgb, u2, K, tau, h, d2);
+    gumbel_softmax_row<true>(lgb, u1, K, tau, h, d1);
+    if (G.sym_N > 0) gumbel_softmax_row<true>(lgb, u2, K, tau, h, d2);
     if (r.live) {
       float* frow = G.edge_feat + (size_t)r.row * K;
       T* dist = reinterpret_cast<T*>(G.dist);

@@ -131,41 +131,92 @@ __device__ __forceinline__ int find_group(const GroupTable<G>& t, int wg) {
 
 // Gumbel softmax over the K logits of a row whose features are split over its two lanes (j, h=0/1):
 // d[r] = softmax_f((lg_f + g_f) / tau), g = -log(eps - log(u + eps))   (MS_HGNN_batch.py:446-473).
+// Registers 4..7 of a lane hold features 8..15: with K <= 8 types nothing there is live and the (uniform) branch skips
+// their logarithms and exponentials.  FAST (bf16-storage kernels only): hardware log2 / exp2 based __logf / __expf.
+template <bool FAST = false>
 __device__ __forceinline__ void gumbel_softmax_row(const f32x16& lg, const float (&u)[8], int K, float tau, int h,
                                                    float (&d)[8]) {
   const float eps = 1e-10f;  // MS_HGNN_batch.py:446
   float y[8];
   float m = -INFINITY;
+  const bool hi = K > 8;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const float g = -logf(eps - logf(u[r] + eps));
-    y[r] = (lg[r] + g) / tau;
-    if (feat_of(r, h) < K) m = fmaxf(m, y[r]);
+  for (int g = 0; g < 2; ++g) {
+    if (g == 0 || hi) {
+#pragma unroll
+      for (int r = 4 * g; r < 4 * g + 4; ++r) {
+        const float gg = FAST ? -__logf(eps - __logf(u[r] + eps)) : -logf(eps - logf(u[r] + eps));
+        y[r] = (lg[r] + gg) / tau;
+        if (feat_of(r, h) < K) m = fmaxf(m, y[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 4 * g; r < 4 * g + 4; ++r) y[r] = 0.f;
+    }
   }
   m = fmaxf(m, __shfl_xor(m, 32, GN_WAVE));
   float s = 0.f;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    d[r] = (feat_of(r, h) < K) ? expf(y[r] - m) : 0.f;
-    s += d[r];
+  for (int g = 0; g < 2; ++g) {
+    if (g == 0 || hi) {
+#pragma unroll
+      for (int r = 4 * g; r < 4 * g + 4; ++r) {
+        d[r] = (feat_of(r, h) < K) ? (FAST ? __expf(y[r] - m) : expf(y[r] - m)) : 0.f;
+        s += d[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 4 * g; r < 4 * g + 4; ++r) d[r] = 0.f;
+    }
   }
   s += __shfl_xor(s, 32, GN_WAVE);
 #pragma unroll
   for (int r = 0; r < 8; ++r) d[r] = d[r] / s;
 }
 
-// uniforms of this lane's features for ordered row `orow`: from U, or from the Philox stream
+// uniforms of this lane's features for ordered row `orow`: from U, or from the Philox stream.  A lane's features come
+// in two runs of four consecutive stream positions (registers 0..3 and 4..7): each run lies in at most two Philox
+// blocks, which are evaluated once and shared by the run's elements (one block per ELEMENT was 4 evaluations per run).
 __device__ __forceinline__ void fetch_uniforms(const float* __restrict__ U, unsigned long long base,
                                                unsigned long long seed, long long orow, int K, int h, float (&u)[8]) {
+  if (U != nullptr) {
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int f = feat_of(r, h);
-    if (f >= K)
-      u[r] = 0.5f;
-    else if (U != nullptr)
-      u[r] = U[(size_t)orow * K + f];
-    else
-      u[r] = gn_philox_uniform_at(base + (unsigned long long)orow * K + f, seed);
+    for (int r = 0; r < 8; ++r) {
+      const int f = feat_of(r, h);
+      u[r] = f < K ? U[(size_t)orow * K + f] : 0.5f;
+    }
+    return;
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int f0 = 8 * g + 4 * h;                           // feat_of(4 g, h)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[4 * g + j] = 0.5f;
+    if (f0 < K) {
+      const unsigned long long pos0 = base + (unsigned long long)orow * K + f0;
+      const int o = (int)(pos0 & 3ull);
+      uint32_t w[8];
+      {
+        uint32_t c[4];
+        gn_philox_block(pos0 >> 2, seed, c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = c[i];
+      }
+#pragma unroll
+      for (int i = 4; i < 8; ++i) w[i] = 0u;
+      if (o + min(K - f0, 4) > 4) {                         // the run crosses into the next block
+        uint32_t c[4];
+        gn_philox_block((pos0 >> 2) + 1ull, seed, c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[4 + i] = c[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // word o + j of w[0..7]
+        const uint32_t a0 = o == 0 ? w[j] : (o == 1 ? w[j + 1] : (o == 2 ? w[j + 2] : w[j + 3]));
+        if (f0 + j < K) u[4 * g + j] = gn_philox_to_uniform(a0);
+      }
+    }
   }
 }
 

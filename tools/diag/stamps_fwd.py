@@ -39,8 +39,10 @@ def report(tag, n_units, groups=None):
         pro = u[:, 1] - u[:, 0]
         body = u[:, 2] - u[:, 1]
         tail = u[:, 4] - u[:, 2]
+        mid = u[:, 3] - u[:, 2]
+        epi = u[:, 4] - u[:, 3]
         print(f"  {name:10s} n={len(u):5d} start med/max {np.median(start):5.2f}/{start.max():5.2f}  end med/max {np.median(end):5.2f}/{end.max():5.2f} us |"
-              f" cycles: prologue {np.median(pro):6.0f}  body med {np.median(body):6.0f} min {body.min():6.0f} max {body.max():6.0f}  tail {np.median(tail):6.0f}")
+              f" cycles: prologue {np.median(pro):6.0f}  body med {np.median(body):6.0f} min {body.min():6.0f} max {body.max():6.0f}  tail {np.median(tail):6.0f} (2->3 {np.median(mid):6.0f}, 3->4 {np.median(epi):6.0f})")
 
 calls = []
 orig = {}
