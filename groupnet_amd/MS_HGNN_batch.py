@@ -541,7 +541,7 @@ class _MessagePassing(nn.Module):
 
 
 def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor], Hs: Sequence[Optional[Tensor]],
-                        noises: Sequence, outs: Sequence[Optional[Tensor]], traces=None
+                        noises: Sequence, outs: Sequence[Optional[Tensor]], traces=None, join=None
                         ) -> List[Tuple[Tensor, Tensor]]:
     """The message-passing rounds of SEVERAL modules over the same scenes, stage by stage, each stage
     ONE grouped launch (model/MS_HGNN_batch.py:174-195 and :425-441 for every module at once).
@@ -551,7 +551,9 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
     optionally receives node_feat.  Returns [(node_feat, factors)] per module.  All modules must
     share nmp_layers and bottleneck_dim (they do in every caller of the reference).
     `traces` (training): one `backward.ModuleTrace` per module, which receives the node features entering
-    every round and the dist every round sampled — all the backward needs besides the inputs."""
+    every round and the dist every round sampled — all the backward needs besides the inputs.
+    `join`: called once after the first node stage has been launched and before anything reads Hs (a caller that
+    builds the incidences on a forked stream joins it here)."""
     n = len(mods)
     if not (n == len(hs) == len(Hs) == len(noises) == len(outs)) or n == 0:
         raise ValueError("run_message_passing: one h, H, noise and out per module")
@@ -589,6 +591,8 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
                   if (sy and not twin) else None) for m, sy in zip(mods, syms)]
         xpq, As = ops.node_stage_grouped([(x, pk) for x, pk in zip(xs, pks)], keep, specs)
         pair_A[:] = As
+        if join is not None and idx == 0:
+            join()       # the incidences were built on a forked stream beside the node stage (graph capture)
         edges = ops.node2edge_grouped([(xp, pq, H, pk["w2"], pk["b2"], sy)
                                        for (xp, pq), H, pk, sy in zip(xpq, Hs, pks, syms)])
         if traces is not None:      # kept for the backward: nothing of this round is re-computed there

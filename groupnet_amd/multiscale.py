@@ -16,6 +16,7 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import contextlib
 import torch
 import torch.nn as nn
 
@@ -53,6 +54,17 @@ def multiscale_autograd(pair: MS_HGNN_oridinary, hypers: Sequence[MS_HGNN_hyper]
     params = [p for m in mods for p in _plist(m)]
     res = MSHGNNFunction.apply(mods, (None, *Hs), nz, *([f] * (1 + S)), *params)
     return torch.cat([f, *res[0::2]], dim=-1), new_H
+
+
+_FORK_STREAMS = {}
+
+
+def _fork_stream(device: torch.device) -> "torch.cuda.Stream":
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _FORK_STREAMS.get(key)
+    if st is None:
+        st = _FORK_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 class MultiScaleHGNN(nn.Module):
@@ -115,11 +127,24 @@ class MultiScaleHGNN(nn.Module):
             raise ValueError(f"noise_u: need {1 + S} entries (pairwise + one per scale)")
         final = torch.empty((B, N, self.out_features), dtype=f.dtype, device=f.device)
         cols = [final[..., D * (1 + i):D * (2 + i)] for i in range(1 + S)]   # written in place by the last MLP
+        join = None
         if S and ops.fused_affinity_fits(N, D):
-            # one launch: affinity, incidence of every scale, f -> final[..., :D], cat(H_s), Philox bump
-            _, Hs, new_H = ops.affinity_topk(f, self.hyper_scales, want_corr=False, f_out=final[..., :D],
-                                             want_H_cat=True, counter=advance[0] if advance else None,
-                                             counter_add=advance[1] if advance else 0)
+            # one launch: affinity, incidence of every scale, f -> final[..., :D], cat(H_s), Philox bump.
+            # The node stage of the first round needs only f: inside a graph capture the two launches are forked
+            # (the graph then runs them side by side; eager launches stay on one stream)
+            # — worth it only when the launches are long: at B*N = 5.6 k rows the extra graph edges cost more
+            # (+9 us per replay) than the 7-us overlap saves; at 51 k rows the replay is 33 us shorter
+            fork = self.grouped and f.is_cuda and B * N >= 32768 and torch.cuda.is_current_stream_capturing()
+            main = torch.cuda.current_stream(f.device) if fork else None
+            side = _fork_stream(f.device) if fork else None
+            if fork:
+                side.wait_stream(main)
+            with (torch.cuda.stream(side) if fork else contextlib.nullcontext()):
+                _, Hs, new_H = ops.affinity_topk(f, self.hyper_scales, want_corr=False, f_out=final[..., :D],
+                                                 want_H_cat=True, counter=advance[0] if advance else None,
+                                                 counter_add=advance[1] if advance else 0)
+            if fork:
+                join = lambda: main.wait_stream(side)
         elif S:
             # large N (N*(N+68)*4 B > LDS tile): banded affinity and banded top-k launches, plain copies
             Hs = ops.topk_incidence(ops.affinity(f if f.dtype == torch.float32 else f.float()), self.hyper_scales)
@@ -136,7 +161,7 @@ class MultiScaleHGNN(nn.Module):
         if self.grouped:
             # every stage of the 1+S modules in ONE launch: launches always carry enough workgroups
             # to fill the chip, and nothing depends on how streams map to hardware queues
-            run_message_passing(mods, [f] * (1 + S), [None, *Hs], list(noise_u), cols)
+            run_message_passing(mods, [f] * (1 + S), [None, *Hs], list(noise_u), cols, join=join)
         else:
             for m, H, u, c in zip(mods, [None, *Hs], noise_u, cols):
                 run_message_passing([m], [f], [H], [u], [c])
