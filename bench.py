@@ -97,7 +97,8 @@ def pmc_traffic(kernel_prefixes, cfg_name):
         ks = json.load(open(files[-1]))["kernels"]
         tot = 0
         for pre in kernel_prefixes:
-            hit = [v for k, v in ks.items() if k.startswith(pre)]
+            alts = pre if isinstance(pre, (tuple, list)) else (pre,)     # alternatives: the one launched most often
+            hit = [v for k, v in ks.items() if any(k.startswith(a) for a in alts)]
             if not hit:
                 return None, name
             tot += max(hit, key=lambda v: v.get("launches", 0))["hbm_bytes"]
@@ -379,7 +380,9 @@ def main():
             dom = max(summ, key=lambda k: summ[k][0])       # the kernel with the largest launch time
             ms, fl, nl = summ[dom]
             ach = fl / (ms * 1e-3) / 1e12
-            traffic, tfile = pmc_traffic([{"agg_mlp_kernel": "agg_x_kernel", "edge_mlp_gumbel_kernel": "edge_x_kernel",
+            # (the stage's device kernel: large bf16 launches run the two-row-blocks-per-wave kernels)
+            traffic, tfile = pmc_traffic([{"agg_mlp_kernel": ("agg_x_kernel", "agg_rb2_kernel"),
+                                           "edge_mlp_gumbel_kernel": ("edge_x_kernel", "edge_rb2_kernel"),
                                            "node_stage_kernel": "node_stage_kernel", "mlp2_kernel": "mlp2_x_kernel"}.get(dom, dom)],
                                          args.config)
             roof = dict(kernel=dom + {"agg_mlp_kernel": " (typed aggregation MLP, all modules in one grouped launch)",

@@ -26,6 +26,39 @@ constexpr int kMaxDescs = 16;
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+// fp32 -> three bf16 parts per value (round to nearest, remainders exact in fp32), eight values at a time, written
+// pair by pair so that every conversion is one two-source v_cvt_pk_bf16_f32.  x = p1 + p2 + p3 to 2^-24 |x|.
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gbf16x2 __attribute__((ext_vector_type(2)));
+typedef float gf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split8(const float (&v)[8], gbf16x8& p1, gbf16x8& p2, gbf16x8& p3) {
+  gu32x4 q1, q2, q3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const gf32x2 x = {v[2 * j], v[2 * j + 1]};
+    const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, gbf16x2));
+    const gf32x2 r1 = {x[0] - __builtin_bit_cast(float, u1 << 16), x[1] - __builtin_bit_cast(float, u1 & 0xffff0000u)};
+    const unsigned u2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, gbf16x2));
+    const gf32x2 r2 = {r1[0] - __builtin_bit_cast(float, u2 << 16), r1[1] - __builtin_bit_cast(float, u2 & 0xffff0000u)};
+    q1[j] = u1;
+    q2[j] = u2;
+    q3[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, gbf16x2));
+  }
+  p1 = __builtin_bit_cast(gbf16x8, q1);
+  p2 = __builtin_bit_cast(gbf16x8, q2);
+  p3 = __builtin_bit_cast(gbf16x8, q3);
+}
+// acc += a . b from the parts: the six significant part-products, smallest first (as the forward's mfma_substep<3>)
+__device__ __forceinline__ void mfma_x6(const gbf16x8 (&a)[3], const gbf16x8 (&b)[3], floatx16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
 // one GEMM problem of a grouped launch (by value in the kernarg segment)
 struct GemmDesc {
   const float* A;
@@ -121,7 +154,7 @@ __device__ __forceinline__ void fetch_b4(f32x4 (&vb)[kB4], const float* __restri
   }
 }
 
-template <bool TA, bool TB, bool FAST>
+template <bool TA, bool TB, bool FAST, bool X6>
 __device__ __forceinline__ void gemm_body(const GemmDesc& D, float (&As)[BK][BM + 4], float (&Bs)[BK][BN + 4]) {
   const int local = (int)blockIdx.x - D.tile0;
   const int split = local / D.gmn, t = local - split * D.gmn;
@@ -208,7 +241,33 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& D, float (&As)[BK][BM 
 #pragma unroll
       for (int kk = 0; kk < BK; ++kk) cs += As[kk][tid];
     }
-    if (!transC) {
+    if constexpr (X6) {
+      // fp32-accurate products on the bf16 matrix cores: per 16-deep k-step a lane reads its 8 k-values of the A row
+      // and of the two B columns (k = ks + 8 hi + j: any mapping works as long as A and B agree), splits them into
+      // three bf16 parts and issues 2 x 6 MFMAs (16x the fp32 instruction's rate: the splitting, ~130 VALU per
+      // k-step, is what bounds this loop)
+#pragma unroll
+      for (int ks = 0; ks < BK; ks += 16) {
+        float av[8], b0v[8], b1v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          av[j] = As[ks + 8 * hi + j][wave * 32 + l31];
+          b0v[j] = Bs[ks + 8 * hi + j][l31];
+          b1v[j] = Bs[ks + 8 * hi + j][32 + l31];
+        }
+        gbf16x8 ap[3], bp0[3], bp1[3];
+        split8(av, ap[0], ap[1], ap[2]);
+        split8(b0v, bp0[0], bp0[1], bp0[2]);
+        split8(b1v, bp1[0], bp1[1], bp1[2]);
+        if (!transC) {
+          mfma_x6(ap, bp0, acc0);
+          mfma_x6(ap, bp1, acc1);
+        } else {    // operands swapped: the accumulators hold the transposed tile (lanes run along m)
+          mfma_x6(bp0, ap, acc0);
+          mfma_x6(bp1, ap, acc1);
+        }
+      }
+    } else if (!transC) {
 #pragma unroll 4
       for (int kk = 0; kk < BK; kk += 2) {
         const float a = As[kk + hi][wave * 32 + l31];
@@ -274,7 +333,7 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& D, float (&As)[BK][BM 
 // k-major so that either storage order of A and B loads coalesced.  Two kernels so that each keeps its own
 // register budget: the vector-staging one (16-byte aligned operands, K a multiple of 32 — every large
 // problem of the backward) runs 4 workgroups per CU; the scalar one takes anything.
-template <bool FAST>
+template <bool FAST, bool X6>
 __device__ __forceinline__ void gemm_dispatch(const GemmTable& T, float (&As)[BK][BM + 4], float (&Bs)[BK][BN + 4]) {
   int g = 0;
   for (int i = 1; i < T.n; ++i)
@@ -282,22 +341,30 @@ __device__ __forceinline__ void gemm_dispatch(const GemmTable& T, float (&As)[BK
   g = gn_uniform(g);
   const GemmDesc& D = T.d[g];
   const int tt = gn_uniform(D.flags & (GN_GEMM_TRANS_A | GN_GEMM_TRANS_B));
-  if (tt == 0) gemm_body<false, false, FAST>(D, As, Bs);
-  else if (tt == GN_GEMM_TRANS_A) gemm_body<true, false, FAST>(D, As, Bs);
-  else if (tt == GN_GEMM_TRANS_B) gemm_body<false, true, FAST>(D, As, Bs);
-  else gemm_body<true, true, FAST>(D, As, Bs);
+  if (tt == 0) gemm_body<false, false, FAST, X6>(D, As, Bs);
+  else if (tt == GN_GEMM_TRANS_A) gemm_body<true, false, FAST, X6>(D, As, Bs);
+  else if (tt == GN_GEMM_TRANS_B) gemm_body<false, true, FAST, X6>(D, As, Bs);
+  else gemm_body<true, true, FAST, X6>(D, As, Bs);
 }
 
 __global__ __launch_bounds__(kB, 4) void gemm_mfma_kernel(const GemmTable T) {
   __shared__ float As[BK][BM + 4];
   __shared__ float Bs[BK][BN + 4];
-  gemm_dispatch<true>(T, As, Bs);
+  gemm_dispatch<true, false>(T, As, Bs);
+}
+
+// the same tiles with the products formed on the bf16 matrix cores from three-part splits (fp32-accurate, like the
+// forward's P = 3 kernels): the default for the vector-staged problems; GN_GEMM_X6=0 selects the fp32-core kernel
+__global__ __launch_bounds__(kB, 3) void gemm_x6_kernel(const GemmTable T) {
+  __shared__ float As[BK][BM + 4];
+  __shared__ float Bs[BK][BN + 4];
+  gemm_dispatch<true, true>(T, As, Bs);
 }
 
 __global__ __launch_bounds__(kB) void gemm_mfma_edge_kernel(const GemmTable T) {
   __shared__ float As[BK][BM + 4];
   __shared__ float Bs[BK][BN + 4];
-  gemm_dispatch<false>(T, As, Bs);
+  gemm_dispatch<false, false>(T, As, Bs);
 }
 
 __global__ __launch_bounds__(kB) void scale_kernel(float* __restrict__ C, long long total, int N, int ldc, float beta) {
@@ -691,7 +758,9 @@ extern "C" int gn_gemm_grouped_f32(const gn_gemm_desc_t* descs, int n, gn_stream
   T[0].n = T[1].n = 0;
   auto flush = [&](int which) {
     if (T[which].n == 0) return;
-    if (which == 0) hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)tiles[0]), dim3(kB), 0, s, T[0]);
+    static const bool x6 = !(getenv("GN_GEMM_X6") && atoi(getenv("GN_GEMM_X6")) == 0);
+    if (which == 0 && x6) hipLaunchKernelGGL(gemm_x6_kernel, dim3((unsigned)tiles[0]), dim3(kB), 0, s, T[0]);
+    else if (which == 0) hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)tiles[0]), dim3(kB), 0, s, T[0]);
     else hipLaunchKernelGGL(gemm_mfma_edge_kernel, dim3((unsigned)tiles[1]), dim3(kB), 0, s, T[1]);
     T[which].n = 0;
     tiles[which] = 0;
