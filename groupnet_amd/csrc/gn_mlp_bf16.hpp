@@ -678,6 +678,9 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
     // tile 0 after t == 3) is interleaved with the MFMAs of B_t; the pre-activations it needs were loaded one tile
     // earlier still.
     const int N = G.N, Pn = G.E;
+    // The pair-form waves are the launch's critical path (they end ~15 us after the hyper modules' waves at B = 512):
+    // where one shares a SIMD with a two-layer wave its instructions issue first.  Measured: 57 -> 52 us.
+    __builtin_amdgcn_s_setprio(1);
     int i, j;
     {
       const int b = rb.row_ld / Pn, p = rb.row_ld - b * Pn;
