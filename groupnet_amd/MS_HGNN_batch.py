@@ -26,6 +26,7 @@ from __future__ import annotations
 import warnings
 from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
 
+import os
 import torch
 import torch.nn as nn
 
@@ -34,7 +35,8 @@ from . import ops
 Tensor = torch.Tensor
 _HDIM_EXTEND = 64      # model/MS_HGNN_batch.py:72,292
 _GUMBEL_TAU = 0.5      # model/MS_HGNN_batch.py:45
-_FUSED_GATHER_MAX_N = 16   # beyond this the stand-alone gather / scatter kernels (LDS-tiled, high occupancy) beat a per-lane
+_FUSED_GATHER_MAX_N = 16
+_FUSE_POOL = os.environ.get("GN_FUSE_POOL", "1") != "0"   # node->edge pooling inside the edge kernel (inference)   # beyond this the stand-alone gather / scatter kernels (LDS-tiled, high occupancy) beat a per-lane
                            # scan of H rows / a per-lane gather of N feature rows in the prologue of an MFMA kernel (latency-bound
                            # at 1-2 waves per SIMD: 311 us vs ~100 us for the closing MLP at N = 50, B = 1024)
 
@@ -593,8 +595,19 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
         pair_A[:] = As
         if join is not None and idx == 0:
             join()       # the incidences were built on a forked stream beside the node stage (graph capture)
-        edges = ops.node2edge_grouped([(xp, pq, H, pk["w2"], pk["b2"], sy)
-                                       for (xp, pq), H, pk, sy in zip(xpq, Hs, pks, syms)])
+        # Inference: the pooled edge rows feed only the edge MLP, so its kernel forms them itself (ops.PoolSpec) and
+        # `edges` never exists in HBM — always for the pairwise graph, for hyper modules up to ops.POOL_MAX_N nodes;
+        # larger hyper modules (and training, whose backward reads `edges`) keep the node2edge launch.
+        fuse = [_FUSE_POOL and traces is None and (twin or ops.BF16X6) and (sy or N <= ops.POOL_MAX_N) for sy in syms]
+        edges: List = [None] * n
+        rest = [i for i in range(n) if not fuse[i]]
+        if rest:
+            for i, e in zip(rest, ops.node2edge_grouped([(xpq[i][0], xpq[i][1], Hs[i], pks[i]["w2"], pks[i]["b2"], syms[i])
+                                                         for i in rest])):
+                edges[i] = e
+        for i in range(n):
+            if fuse[i]:
+                edges[i] = ops.PoolSpec(xpq[i][0], xpq[i][1], Hs[i], pks[i]["w2"], pks[i]["b2"], syms[i])
         if traces is not None:      # kept for the backward: nothing of this round is re-computed there
             for t, kd, (xp, pq), e in zip(traces, keep, xpq, edges):
                 t.n2e.append(dict(x1=kd["hid"], xp=xp, pq=pq, edges=e))

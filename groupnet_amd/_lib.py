@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -37,7 +37,8 @@ class N2EGroup(ctypes.Structure):       # gn_n2e_group_t
 class EdgeGroup(ctypes.Structure):      # gn_edge_group_t
     _fields_ = [("edges", _P), ("U", _P), ("W", _P), ("bias", _P), ("edge_feat", _P), ("dist", _P),
                 ("philox_offset", _U64), ("rows", _I), ("K", _I), ("sym_N", _I), ("keep_z1", _P), ("keep_z", _P),
-                ("keep_dh1", _P), ("keep_lgf", _P), ("Wx", _P)]
+                ("keep_dh1", _P), ("keep_lgf", _P), ("Wx", _P), ("xp", _P), ("pq", _P), ("pool_H", _P), ("w2", _P),
+                ("b2", _P), ("pool_N", _I), ("pool_E", _I)]
 
 
 class GatherGroup(ctypes.Structure):    # gn_gather_group_t

@@ -514,7 +514,10 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void edge_x_kernel(Gro
   GN_STAMP(unit, 0);
   GN_STAMP(unit, 8);
   f32x16 in[2], z[2], lg;
-  load_rows<2>(reinterpret_cast<const T*>(G.edges), GN_FEAT, rb.row_ld, h, in);
+  if (G.edges != nullptr)
+    load_rows<2>(reinterpret_cast<const T*>(G.edges), GN_FEAT, rb.row_ld, h, in);
+  else
+    pooled_rows<T>(G, rb.row_ld, h, in);       // fused node -> edge pooling
   // ordered edge rows whose uniforms this row consumes: itself, or — symmetric pairwise form — the two ordered
   // edges (i,j) and (j,i) of its unordered pair
   long long o1 = rb.row_ld, o2 = rb.row_ld;
@@ -1128,7 +1131,10 @@ __global__ __launch_bounds__(256, 2) void edge_rb2_kernel(GroupTable<gn_edge_gro
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
     f32x16 in[2];
-    load_rows<2>(reinterpret_cast<const T*>(G.edges), GN_FEAT, rb[b].row_ld, h, in);
+    if (G.edges != nullptr)
+      load_rows<2>(reinterpret_cast<const T*>(G.edges), GN_FEAT, rb[b].row_ld, h, in);
+    else
+      pooled_rows<T>(G, rb[b].row_ld, h, in);  // fused node -> edge pooling
     make_parts_tiles<1, 2>(in, xi[b]);
   }
   f32x16 bias_n = load_bias_tile(bi0, h), bias_nn = load_bias_tile(bi0 + 32, h);

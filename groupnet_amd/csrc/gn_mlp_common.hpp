@@ -220,6 +220,149 @@ __device__ __forceinline__ void fetch_uniforms(const float* __restrict__ U, unsi
   }
 }
 
+// ---- fused node -> edge pooling: the rows of the edge MLP formed on the fly (gn_edge_group_t.xp) -------------------
+// Lane (row, h) of a 32-row block produces its 32 features of edges[row] exactly as node2edge_kernel writes them
+// (MS_HGNN_batch.py:127-141, 359-370; decomposed attention  att[e,n] = w2 . relu(P_n + (H Qn)_e) + b2).  The 32
+// attention channels are split over the row's two lanes (16 each, one shuffle per logit), the node rows are read
+// straight from L2 (xp / pq of a launch are a few MB).
+template <typename T>
+__device__ __forceinline__ void load16(const T* __restrict__ p, float (&v)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 x = ld4(p + 4 * q);
+    v[4 * q] = x[0], v[4 * q + 1] = x[1], v[4 * q + 2] = x[2], v[4 * q + 3] = x[3];
+  }
+}
+// acc[t][4q + c] += w * x[32 t + 8 q + 4 h + c]
+template <typename T>
+__device__ __forceinline__ void axpy_row(const T* __restrict__ x, float w, int h, f32x16 (&acc)[2], bool first) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = ld4(x + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[t][4 * q + c] = first ? w * v[c] : fmaf(w, v[c], acc[t][4 * q + c]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void pooled_rows(const gn_edge_group_t& G, int row, int h, f32x16 (&in)[2]) {
+  const int N = G.pool_N;
+  const T* xp = reinterpret_cast<const T*>(G.xp);
+  const T* pq = reinterpret_cast<const T*>(G.pq);
+  float w2[16];
+  load16(G.w2 + 16 * h, w2);
+  const float b2v = *G.b2;
+  if (G.pool_H == nullptr) {
+    int b, i, j;
+    if (G.sym_N > 0) {
+      const int Pn = gn_pair_count(N);
+      b = row / Pn;
+      gn_pair_decode(row - b * Pn, N, i, j);
+    } else {
+      b = row / (N * N);
+      const int e = row - b * N * N;
+      i = e / N;
+      j = e - i * N;
+    }
+    const T* pi = pq + ((size_t)b * N + i) * GN_FEAT + 16 * h;
+    const T* pj = pq + ((size_t)b * N + j) * GN_FEAT + 16 * h;
+    float Pi[16], Qi[16], Pj[16], Qj[16];
+    load16(pi, Pi);
+    load16(pi + 32, Qi);
+    load16(pj, Pj);
+    load16(pj + 32, Qj);
+    float ai = 0.f, aj = 0.f;
+    float wi, wj;
+    if (i == j) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) ai = fmaf(w2[c], fmaxf(Pi[c] + 2.f * Qi[c], 0.f), ai);
+      ai += __shfl_xor(ai, 32, GN_WAVE);
+      ai += b2v;
+      // H = 2 on the self-loop: v = 2*att, the other N-1 nodes contribute exp(0)
+      const float v = 2.f * ai;
+      const float mx = N > 1 ? fmaxf(v, 0.f) : v;
+      const float ev = expf(v - mx);
+      const float sum = ev + gn_nonmember_sum(N - 1, mx);
+      wi = ev / sum * 2.f;
+      wj = 0.f;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float q = Qi[c] + Qj[c];
+        ai = fmaf(w2[c], fmaxf(Pi[c] + q, 0.f), ai);
+        aj = fmaf(w2[c], fmaxf(Pj[c] + q, 0.f), aj);
+      }
+      ai += __shfl_xor(ai, 32, GN_WAVE);
+      aj += __shfl_xor(aj, 32, GN_WAVE);
+      ai += b2v;
+      aj += b2v;
+      const float mx = N > 2 ? fmaxf(fmaxf(ai, aj), 0.f) : fmaxf(ai, aj);
+      const float ei = expf(ai - mx), ej = expf(aj - mx);
+      const float sum = (ei + ej) + gn_nonmember_sum(N - 2, mx);
+      wi = ei / sum;
+      wj = ej / sum;
+    }
+    axpy_row(xp + ((size_t)b * N + i) * GN_FEAT, wi, h, in, true);
+    axpy_row(xp + ((size_t)b * N + j) * GN_FEAT, wj, h, in, false);
+    return;
+  }
+  // hyper module (N <= 16): members = nodes with H != 0
+  constexpr int NMAX = 16;
+  const int b = row / G.pool_E;
+  const float* Hrow = G.pool_H + (size_t)row * N;
+  const T* pqb = pq + (size_t)b * N * GN_FEAT + 16 * h;
+  float hv[NMAX];
+  float Q[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) Q[c] = 0.f;
+  int cnt = 0;
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    hv[n] = n < N ? Hrow[n] : 0.f;
+    if (hv[n] != 0.f) {
+      ++cnt;
+      float Qn[16];
+      load16(pqb + (size_t)n * GN_FEAT + 32, Qn);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) Q[c] = fmaf(hv[n], Qn[c], Q[c]);
+    }
+  }
+  float v[NMAX];
+  float mx = cnt < N ? 0.f : -INFINITY;
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    v[n] = 0.f;
+    float t = 0.f;
+    if (hv[n] != 0.f) {
+      float Pn[16];
+      load16(pqb + (size_t)n * GN_FEAT, Pn);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) t = fmaf(w2[c], fmaxf(Pn[c] + Q[c], 0.f), t);
+    }
+    t += __shfl_xor(t, 32, GN_WAVE);       // (both lanes of a row take the same branches: H is per row)
+    if (hv[n] != 0.f) {
+      v[n] = (t + b2v) * hv[n];
+      mx = fmaxf(mx, v[n]);
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n)
+    if (hv[n] != 0.f) {
+      v[n] = expf(v[n] - mx);
+      sum += v[n];
+    }
+  sum += gn_nonmember_sum(N - cnt, mx);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) in[t][r] = 0.f;
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n)
+    if (hv[n] != 0.f) axpy_row(xp + ((size_t)b * N + n) * GN_FEAT, v[n] / sum * hv[n], h, in, false);
+}
+
 // The 16 pre-activation values lane (j,h) needs of hidden tile t of type k for ONE node: A row + offset.
 struct PreTile {
   f32x4 v[4];

@@ -918,7 +918,22 @@ static int edge_launch(const gn_edge_group_t* groups, int n_groups, float tau, u
   int wg = 0;
   for (int g = 0; g < n_groups; ++g) {
     const gn_edge_group_t& G = groups[g];
-    GN_CHECK(need(G.edges, true));
+    if (G.edges != nullptr) {
+      GN_CHECK(need(G.edges, true));
+    } else {      // fused node -> edge pooling: bf16-core kernels only, nothing kept for a backward
+      if (!xm || G.keep_z1 || G.keep_z || G.keep_dh1 || G.keep_lgf) return GN_ERR_NULL;
+      GN_CHECK(need(G.xp, true));
+      GN_CHECK(need(G.pq, true));
+      GN_CHECK(need(G.w2, true));
+      GN_CHECK(need(G.b2, false));
+      if (G.pool_N <= 0) return GN_ERR_SHAPE;
+      if (G.pool_H == nullptr) {
+        const long long per = G.sym_N > 0 ? gn_pair_count(G.pool_N) : (long long)G.pool_N * G.pool_N;
+        if ((G.sym_N > 0 && G.sym_N != G.pool_N) || G.rows % per != 0) return GN_ERR_SHAPE;
+      } else {
+        if (G.sym_N != 0 || G.pool_N > 16 || G.pool_E <= 0 || G.rows % G.pool_E != 0) return GN_ERR_SHAPE;
+      }
+    }
     GN_CHECK(need(xm ? G.Wx : (const void*)G.W, true));
     GN_CHECK(need(G.bias, true));
     GN_CHECK(need(G.edge_feat, false));

@@ -519,9 +519,28 @@ class PhiloxNoise:
         self.seed, self.offset, self.counter = int(seed) & (2**64 - 1), int(offset), counter
 
 
+class PoolSpec:
+    """Rows of the edge MLP to be formed inside its kernel instead of read from an `edges` tensor: the
+    attention-weighted node -> edge pooling of `node2edge` (xp, pq (B,N,64) from the node stage; H (B,E,N) or None =
+    the implicit pairwise graph, sym -> unordered pairs; w2 (32,), b2 (1,)).  bf16-core kernels only; H needs N <= 16
+    (run_message_passing uses the hyper form only up to POOL_MAX_N)."""
+    __slots__ = ("xp", "pq", "H", "w2", "b2", "sym")
+
+    def __init__(self, xp: Tensor, pq: Tensor, H: Optional[Tensor], w2: Tensor, b2: Tensor, sym: bool = False):
+        self.xp, self.pq, self.H, self.w2, self.b2, self.sym = xp, pq, H, w2, b2, bool(sym)
+
+
+# Hyper modules: largest N whose pooling the edge kernel may form itself (the kernel's bound is 16: a row's incidence
+# stays in registers).  Default 0 = pairwise graph only: without an LDS stage the hyper form pays one L2 latency per
+# member and pass — measured at B=512, N=11: edge kernel +15.7 us against the ~10 us the hyper groups cost in the
+# node2edge launch; the pairwise form costs +3 us and removes 5.5 us (and, at N=50 / B=1024, 2 x 167 MB of traffic).
+POOL_MAX_N = int(os.environ.get("GN_POOL_MAX_N", "0"))
+POOL_KERNEL_MAX_N = 16
+
+
 def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5, keep: Optional[List[dict]] = None
                             ) -> List[Tuple[Tensor, Optional[Tensor]]]:
-    """items = [(edges (B,E,64), U tensor (B,E,K) or PhiloxNoise, pk, K[, sym_N[, want_dist]])];
+    """items = [(edges (B,E,64) or PoolSpec, U tensor (B,E,K) or PhiloxNoise, pk, K[, sym_N[, want_dist]])];
     returns [(edge_feat, dist)].  All PhiloxNoise entries of one call must share seed and counter.
 
     sym_N = N > 0: `edges` holds the (B, N(N+1)/2, 64) unordered-pair rows of the pairwise graph; U /
@@ -530,7 +549,8 @@ def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5, keep: Opti
     ``keep`` (training) receives per group the activations the kernel otherwise holds in registers:
     {"z1" (rows,128), "z" (rows,64), "dh1" (rows,256), "lgf" (rows,32)}."""
     _groups(len(items))
-    e0 = _req(items[0][0], "edges", (None, None, FEAT), _ACT_DTYPES)
+    first = items[0][0]
+    e0 = _req(first.xp if isinstance(first, PoolSpec) else first, "edges", (None, None, FEAT), _ACT_DTYPES)
     dt = e0.dtype
     arr = (_lib.EdgeGroup * len(items))()
     outs = []
@@ -539,9 +559,30 @@ def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5, keep: Opti
         edges, U, pk, K = item[:4]
         sym_N = int(item[4]) if len(item) > 4 else 0
         want_dist = bool(item[5]) if len(item) > 5 else True
-        _req(edges, "edges", (None, None, FEAT), dt)
-        _same_device(e0, edges)
-        B, E, _ = edges.shape
+        pool = edges if isinstance(edges, PoolSpec) else None
+        if pool is not None:
+            if keep is not None or not BF16X6 and not _twin(dt):
+                raise ValueError("PoolSpec: forward-only, bf16-core kernels only")
+            _req(pool.xp, "xp", (None, None, FEAT), dt)
+            B, Np, _ = pool.xp.shape
+            _req(pool.pq, "pq", (B, Np, FEAT), dt)
+            _req(pool.w2, "w2", (32,))
+            _req(pool.b2, "b2", (1,))
+            if pool.H is None:
+                if bool(sym_N) != pool.sym or (sym_N and sym_N != Np):
+                    raise ValueError("PoolSpec: sym must agree with sym_N = N")
+                E = pair_count(Np) if pool.sym else Np * Np
+            else:
+                _req(pool.H, "H", (B, None, Np))
+                if sym_N or Np > POOL_KERNEL_MAX_N:
+                    raise ValueError(f"PoolSpec with H: a hyper module with N <= {POOL_KERNEL_MAX_N}")
+                E = pool.H.shape[1]
+            _same_device(e0, pool.xp, pool.pq, pool.H, pool.w2, pool.b2)
+            edges = pool.xp              # (device / dtype of the outputs)
+        else:
+            _req(edges, "edges", (None, None, FEAT), dt)
+            _same_device(e0, edges)
+            B, E, _ = edges.shape
         if sym_N and E != pair_count(sym_N):
             raise ValueError(f"edges: symmetric form needs {pair_count(sym_N)} pair rows per scene, got {E}")
         Eo = sym_N * sym_N if sym_N else E          # ordered edges per scene (noise / dist layout)
@@ -564,9 +605,12 @@ def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5, keep: Opti
             mk = lambda w: torch.empty((B * E, w), dtype=edges.dtype, device=edges.device)
             keep.append(dict(z1=mk(128), z=mk(64), dh1=mk(256), lgf=mk(32)))
             kp = tuple(keep[-1][n].data_ptr() for n in ("z1", "z", "dh1", "lgf"))
-        arr[g] = _lib.EdgeGroup(edges.data_ptr(), u_ptr, pk["W"].data_ptr(), pk["bias"].data_ptr(),
-                                edge_feat.data_ptr(), 0 if dist is None else dist.data_ptr(), off, B * E, K, sym_N, *kp,
-                                _ximg(pk, "edge", dt))
+        pool_args = (0, 0, 0, 0, 0, 0, 0) if pool is None else (
+            pool.xp.data_ptr(), pool.pq.data_ptr(), 0 if pool.H is None else pool.H.data_ptr(), pool.w2.data_ptr(),
+            pool.b2.data_ptr(), pool.xp.shape[1], 0 if pool.H is None else pool.H.shape[1])
+        arr[g] = _lib.EdgeGroup(0 if pool is not None else edges.data_ptr(), u_ptr, pk["W"].data_ptr(),
+                                pk["bias"].data_ptr(), edge_feat.data_ptr(), 0 if dist is None else dist.data_ptr(), off,
+                                B * E, K, sym_N, *kp, _ximg(pk, "edge", dt), *pool_args)
         outs.append((edge_feat, dist))
     flops = sum(int(a.rows) for a in arr) * 2 * (64 * 128 + 128 * 64 + 64 * 256 + 256 * 32)
     with torch.cuda.device(e0.device), _Probed("edge_mlp_gumbel_kernel", flops):

@@ -250,6 +250,18 @@ typedef struct {
                         layers — per hidden tile t of init_MLP: [Wi0(t,in0), Wi0(t,in1), Wi1(0,t), Wi1(1,t)], then
                         per hidden tile t of [Wd0]: [Wd0(t,in0), Wd0(t,in1), Wd1(0,t)] — 40 tiles = 80 sub-steps.
                         With it W may be NULL. */
+  /* Fused node->edge pooling (bf16-core kernels only, i.e. with Wx): edges == NULL and xp != NULL — every row of
+   * `edges` is formed inside the kernel exactly as gn_node2edge_* would have written it (MS_HGNN_batch.py:127-141,
+   * 359-370) and never touches HBM.  xp / pq: (B*N, 64) outputs of gn_node_mlp_*; w2 (32), b2 (1): attention layer 1;
+   * pool_N = N; pool_H == NULL: the implicit pairwise graph (unordered pairs when sym_N = N, else the N*N ordered
+   * edges); pool_H != NULL: (rows, N) incidence of a hyper module with pool_E hyperedges per scene, N <= 16. */
+  const float* xp;      /* [T] */
+  const float* pq;      /* [T] */
+  const float* pool_H;
+  const float* w2;
+  const float* b2;
+  int pool_N;
+  int pool_E;
 } gn_edge_group_t;
 int gn_edge_mlp_gumbel_f32(const gn_edge_group_t* groups, int n_groups, float tau, unsigned long long seed,
                            const unsigned long long* offset_dev, gn_stream_t stream);

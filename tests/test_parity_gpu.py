@@ -1004,3 +1004,35 @@ def test_bf16_core_paths_match_fp32_mfma_paths_at_full_size():
             ops.BF16X6 = True
     assert torch.equal(Ha, Hb)
     assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+
+
+def test_fused_node2edge_pooling_equals_the_node2edge_launch(monkeypatch):
+    """ops.PoolSpec: the edge kernel forms the pooled edge rows itself (pairwise graph by default; hyper modules when
+    ops.POOL_MAX_N allows) — same outputs as with the node2edge launch and an `edges` tensor in HBM (the 32 attention
+    channels are summed in two halves instead of one chain: 1e-6, incidence and factors included)."""
+    import groupnet_amd.MS_HGNN_batch as M
+    from groupnet_amd import ops
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    torch.manual_seed(21)
+    B, N, scales = 7, 11, [2, 5, 11]
+    blk = MultiScaleHGNN(scales).to(dev()).eval()
+    f = torch.randn(B, N, 64, device=dev())
+    U = [[torch.rand(s, device=dev())] for s in blk.noise_shapes(B, N)]
+    outs = {}
+    with torch.no_grad():
+        for tag, fuse, maxn in (("launch", False, 0), ("pair", True, 0), ("all", True, 16)):
+            monkeypatch.setattr(M, "_FUSE_POOL", fuse)
+            monkeypatch.setattr(ops, "POOL_MAX_N", maxn)
+            outs[tag] = blk(f, noise_u=U)
+        # the modules' own forward (factors) through the fused path
+        monkeypatch.setattr(M, "_FUSE_POOL", True)
+        _, fac_f = blk.interaction(f, noise_u=U[0])
+        monkeypatch.setattr(M, "_FUSE_POOL", False)
+        _, fac_u = blk.interaction(f, noise_u=U[0])
+    ref = outs["launch"]
+    scale = float(ref[0].abs().max())
+    for tag in ("pair", "all"):
+        err = float((outs[tag][0] - ref[0]).abs().max()) / scale
+        print(f"\nfused pooling ({tag}) vs node2edge launch: max rel diff {err:.2e}")
+        assert err <= 1e-6 and torch.equal(outs[tag][1], ref[1])
+    assert float((fac_f - fac_u).abs().max()) <= 1e-6
