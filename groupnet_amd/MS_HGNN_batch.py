@@ -35,10 +35,13 @@ from . import ops
 Tensor = torch.Tensor
 _HDIM_EXTEND = 64      # model/MS_HGNN_batch.py:72,292
 _GUMBEL_TAU = 0.5      # model/MS_HGNN_batch.py:45
-_FUSED_GATHER_MAX_N = 16
-_FUSE_POOL = os.environ.get("GN_FUSE_POOL", "1") != "0"   # node->edge pooling inside the edge kernel (inference)   # beyond this the stand-alone gather / scatter kernels (LDS-tiled, high occupancy) beat a per-lane
-                           # scan of H rows / a per-lane gather of N feature rows in the prologue of an MFMA kernel (latency-bound
-                           # at 1-2 waves per SIMD: 311 us vs ~100 us for the closing MLP at N = 50, B = 1024)
+# Beyond these N the stand-alone gather / scatter kernels (LDS-tiled, high occupancy) beat a per-lane scan of H rows /
+# a per-lane gather of N feature rows in the prologue of an MFMA kernel (latency-bound at 1-2 waves per SIMD; measured
+# again in round 2 at N = 50, B = 1024, bf16: typed MLP 390 -> 439 us against a 38-us gather launch, closing MLP
+# 54 -> 303 us against 71 + 56 us of scatter launches).
+_FUSED_GATHER_MAX_N = int(os.environ.get("GN_FUSED_GATHER_MAX_N", "16"))     # eo = H @ ori inside the typed MLP kernel
+_FUSED_SCATTER_MAX_N = int(os.environ.get("GN_FUSED_SCATTER_MAX_N", "16"))   # cat(H^T feat, ori)/N inside the closing MLP
+_FUSE_POOL = os.environ.get("GN_FUSE_POOL", "1") != "0"   # node->edge pooling inside the edge kernel (inference)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -645,7 +648,7 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
                 src = eos[i]
             items.append((src, edge_feats[i], pk, K))
         feats = ops.agg_mlp_grouped(items)
-        if N <= _FUSED_GATHER_MAX_N:
+        if N <= _FUSED_SCATTER_MAX_N:
             # cat(H^T feat, ori) / N is formed inside the MLP kernel that consumes it
             return [ops.ScatterSpec(f, H, o, sy) for f, H, o, sy in zip(feats, Hs, oris, syms)]
         return ops.agg_scatter_grouped([(f, H, o, sy) for f, H, o, sy in zip(feats, Hs, oris, syms)])
