@@ -609,27 +609,32 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_kernel(ScatterTable T, int
     for (int idx = threadIdx.x; idx < g * E * N; idx += kBlock) s_H[idx] = hs[idx];
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < g * N * 32; idx += kBlock) {
-    const int d = idx & 31, sn = idx >> 5;
+  // every thread a (node, 4 features) item of H^T feat (a zero incidence skips its row: top-k incidences are sparse) ...
+  for (int idx = threadIdx.x; idx < g * N * 16; idx += kBlock) {
+    const int d = idx & 15, sn = idx >> 4;
     const int s = sn / N, n = sn - s * N;
-    f32x4 acc;
-    if (d < 16) {
-      acc = {0.f, 0.f, 0.f, 0.f};
-      const float* hcol = s_H + (size_t)s * E * N + n;
-      const f32x4* f4 = reinterpret_cast<const f32x4*>(s_feat + (size_t)s * E * GN_FEAT) + d;
-      for (int e = 0; e < E; ++e) {
-        const float hv = hcol[(size_t)e * N];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* hcol = s_H + (size_t)s * E * N + n;
+    const f32x4* f4 = reinterpret_cast<const f32x4*>(s_feat + (size_t)s * E * GN_FEAT) + d;
+    for (int e = 0; e < E; ++e) {
+      const float hv = hcol[(size_t)e * N];
+      if (hv != 0.f) {
         const f32x4 v = f4[e * 16];
         acc[0] = fmaf(hv, v[0], acc[0]);
         acc[1] = fmaf(hv, v[1], acc[1]);
         acc[2] = fmaf(hv, v[2], acc[2]);
         acc[3] = fmaf(hv, v[3], acc[3]);
       }
-    } else {
-      acc = ld4(reinterpret_cast<const TS*>(Gr.ori) + ((size_t)(b0 + s) * N + n) * GN_FEAT + 4 * (d - 16));
     }
-    f32x4 r = {acc[0] / fN, acc[1] / fN, acc[2] / fN, acc[3] / fN};
+    const f32x4 r = {acc[0] / fN, acc[1] / fN, acc[2] / fN, acc[3] / fN};
     st4(reinterpret_cast<TS*>(Gr.out) + ((size_t)(b0 + s) * N + n) * 2 * GN_FEAT + 4 * d, r);
+  }
+  // ... then the ori half of the concat
+  for (int idx = threadIdx.x; idx < g * N * 16; idx += kBlock) {
+    const int d = idx & 15, sn = idx >> 4;
+    const f32x4 acc = ld4(reinterpret_cast<const TS*>(Gr.ori) + ((size_t)b0 * N + sn) * GN_FEAT + 4 * d);
+    const f32x4 r = {acc[0] / fN, acc[1] / fN, acc[2] / fN, acc[3] / fN};
+    st4(reinterpret_cast<TS*>(Gr.out) + ((size_t)b0 * N + sn) * 2 * GN_FEAT + GN_FEAT + 4 * d, r);
   }
 }
 
