@@ -1377,4 +1377,379 @@ __global__ __launch_bounds__(256, IT == 4 ? 1 : 2) void mlp2_x_kernel(GroupTable
   GN_STAMP(unit, 9);
 }
 
+
+// =====================================================================================================================
+// Small launches of the closing MLP: the 4 waves of a workgroup SHARE one 32-row block (mlp2_xs_kernel).
+// With fewer row blocks than SIMDs (B*N = 5.6 k rows per module at B = 512: 704 blocks for 4 modules on 1024 SIMDs) a
+// wave that owns a whole chain sits alone on its SIMD and the launch lasts as long as one wave's dependent chain
+// (fused-scatter prologue + HT serial layer-pair slices): 23 us for ~4 us of matrix work.  Here the hidden tiles of the
+// layer pair are dealt over the 4 waves of the row block (wave w takes tiles w, w+4, ...), each wave walks only ITS
+// slices of the (unchanged, pipeline-ordered) weight image through a private register ring, the input operands are
+// formed once per workgroup (wave w forms input tile w) and exchanged through LDS as bf16 parts, and the partial outputs
+// meet in LDS: 4x the waves, each with a quarter of the chain, three workgroups per CU so that the launch is one round.
+// Measured at B = 512 (MI355X, same-session A/B, GN_MLP2_XS = 0 / 1): launch 22.4 -> 14.0 us, single-stream forward
+// 0.158 -> 0.149 ms, overlapped throughput unchanged (5.03 vs 5.00 M scenes/s).
+// The same split of the NODE stage (chain workgroups of 4 waves per row block beside the unchanged per-node typed
+// layer) was built and measured too and is not kept: launch 23.4 -> 22.4 us, overlapped throughput -3 % (4x the weight
+// traffic from L2: a workgroup of one row block streams the whole image for 32 rows instead of 128) — the node stage's
+// critical path is its 132 long "A" workgroups, not the chain.
+// =====================================================================================================================
+
+// A wave's private walk over L sub-steps whose addresses `at(s)` gives (s a compile-time constant after unrolling):
+// a ring of D sub-steps refilled straight from L2.
+template <int P, int L>
+struct PStream {
+  static constexpr int D = P == 3 ? 4 : 8;
+  f32x4 q[D][P];
+  template <typename AT>
+  __device__ __forceinline__ void begin(AT at) {
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+      if (u < L) {
+        const f32x4* src = at(u);
+#pragma unroll
+        for (int p = 0; p < P; ++p) q[u][p] = src[p * 64];
+      }
+  }
+  template <typename AT>
+  __device__ __forceinline__ void step(int s, AT at, const Parts<P>& x, f32x16& acc) {
+    mfma_substep<P>(q[s % D], x, acc);
+    if (s + D < L) {
+      const f32x4* src = at(s + D);
+#pragma unroll
+      for (int p = 0; p < P; ++p) q[s % D][p] = src[p * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);     // (keeps the run-ahead loads where they are issued)
+  }
+};
+
+// sub-step offsets of A_t / B_t inside a pipeline-ordered layer-pair image (A0 A1 B0 A2 B1 ... A(HT-1) B(HT-2) B(HT-1))
+__device__ __forceinline__ int pipe_off_A(int t, int NA, int NB) { return t == 0 ? 0 : NA + (t - 1) * (NA + NB); }
+__device__ __forceinline__ int pipe_off_B(int t, int HT, int NA, int NB) {
+  return t < HT - 1 ? 2 * NA + t * (NA + NB) : HT * NA + (HT - 1) * NB;
+}
+
+template <typename T>
+__device__ __forceinline__ void add_row_tile(const T* __restrict__ src, float w, int h, f32x16& a) {   // src: row + 32*tile
+  const T* p = src + 4 * h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = ld4(p + 8 * q);
+    a[4 * q + 0] = fmaf(w, v[0], a[4 * q + 0]);
+    a[4 * q + 1] = fmaf(w, v[1], a[4 * q + 1]);
+    a[4 * q + 2] = fmaf(w, v[2], a[4 * q + 2]);
+    a[4 * q + 3] = fmaf(w, v[3], a[4 * q + 3]);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void load_row_tile(const T* __restrict__ src, int h, f32x16& a) {          // src: row + 32*tile
+  const T* p = src + 4 * h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = ld4(p + 8 * q);
+    a[4 * q + 0] = v[0];
+    a[4 * q + 1] = v[1];
+    a[4 * q + 2] = v[2];
+    a[4 * q + 3] = v[3];
+  }
+}
+
+// ONE 32-feature tile of the MLP's input row in the MFMA layout, for the cases without a gather worth the name:
+// x[row, 32*tile ..]; tile 2/3 of the fused scatter's input = ori[b,n] / divisor; tile 0/1 for ORDERED pairwise edge
+// rows (2N members, the C ABI's plain form; the engine uses unordered pairs).  Hyper and unordered-pair groups go through
+// scatter_tile_lines below.
+template <typename T>
+__device__ __forceinline__ void mlp2_rows_tile(const gn_mlp2_group_t& G, int row, int h, int N, float divisor, int IT,
+                                               int tile, f32x16& in) {
+  if (G.x != nullptr) {
+    load_row_tile(reinterpret_cast<const T*>(G.x) + (size_t)row * (IT * 32) + 32 * tile, h, in);
+    return;
+  }
+  if (tile >= 2) {
+    load_row_tile(reinterpret_cast<const T*>(G.ori) + (size_t)row * GN_FEAT + 32 * (tile - 2), h, in);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) in[r] = in[r] / divisor;
+    return;
+  }
+  const int E = G.E;
+  const int b = row / N, n = row - b * N;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const T* fb = reinterpret_cast<const T*>(G.feat) + (size_t)b * E * GN_FEAT + 32 * tile;
+  for (int j = 0; j < N; ++j) {
+    add_row_tile(fb + (size_t)(n * N + j) * GN_FEAT, 1.f, h, acc);
+    add_row_tile(fb + (size_t)(j * N + n) * GN_FEAT, 1.f, h, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) in[r] = acc[r] / divisor;
+}
+
+// The fused scatter of one 32-row block, one 128-byte feature tile, in LINE layout: lane L = (sub = L / 8, piece = L % 8)
+// accumulates the 16-byte piece `piece` of the rows rg * 8 + sub (rg = 0..3), so that one load instruction covers 8 whole
+// 128-byte lines.  In the MFMA layout (lane (j, h) = row j, features 8 q + 4 h + c) every load instruction touches 32
+// lines for 16 bytes per lane and every line is looked up by four instructions: the CU's L1 handles one line per clock,
+// and the gather of a row block (11 members x 4 loads x 32 lines per tile) kept it busy for ~12 k cycles, longer than
+// the block's matrix work.  Same members, same order, same fmaf per (row, feature): the sums are bit-identical; the
+// layout changes once, through `scratch` (32 rows x 36 floats, private to the wave: write, barrier, read).
+// Returns false (nothing done) for shapes the per-lane form handles (ordered pairwise edges).
+constexpr int kLinePitch = 36;
+template <typename T, bool hyper>
+__device__ __forceinline__ void scatter_tile_lines_(const gn_mlp2_group_t& G, int blk, int rows, int N, float divisor,
+                                                    int tile, int lane, float* __restrict__ scratch) {
+  const int E = G.E;
+  const int sub = lane >> 3, piece = lane & 7;
+  const int cnt = hyper ? E : N;
+  unsigned fo[4], ho[4];                         // feat / H offsets (elements) of this lane's four rows
+  int nn[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const int r = min(blk * 32 + rg * 8 + sub, rows - 1);
+    const int b = r / N;
+    nn[rg] = r - b * N;
+    fo[rg] = (unsigned)b * E * GN_FEAT + 32 * tile + 4 * piece;
+    ho[rg] = (unsigned)b * E * N + nn[rg];
+  }
+  const T* feat = reinterpret_cast<const T*>(G.feat);
+  f32x4 acc[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int MB = 6;                          // members per batch (their rows are requested together)
+  for (int m0 = 0; m0 < cnt; m0 += MB) {
+    f32x4 v[MB][4];
+    float w[MB][hyper ? 4 : 1];
+#pragma unroll
+    for (int u = 0; u < MB; ++u) {
+      const int m = min(m0 + u, cnt - 1);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int idx = hyper ? m : gn_pair_index(nn[rg], m, N);
+        v[u][rg] = ld4(feat + fo[rg] + (size_t)idx * GN_FEAT);
+        if constexpr (hyper) w[u][rg] = G.H[ho[rg] + (size_t)m * N];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < MB; ++u)
+      if (m0 + u < cnt) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[rg][c] = fmaf(hyper ? w[u][hyper ? rg : 0] : 1.f, v[u][rg][c], acc[rg][c]);
+      }
+  }
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = acc[rg][c] / divisor;
+    *reinterpret_cast<f32x4*>(scratch + (rg * 8 + sub) * kLinePitch + 4 * piece) = o;
+  }
+}
+template <typename T>
+__device__ __forceinline__ bool scatter_tile_lines(const gn_mlp2_group_t& G, int blk, int rows, int N, float divisor,
+                                                   int tile, int lane, float* __restrict__ scratch) {
+  if (G.H != nullptr) scatter_tile_lines_<T, true>(G, blk, rows, N, divisor, tile, lane, scratch);
+  else if (G.sym) scatter_tile_lines_<T, false>(G, blk, rows, N, divisor, tile, lane, scratch);
+  else return false;
+  return true;
+}
+// ... and back in the MFMA layout (after a barrier)
+__device__ __forceinline__ void read_tile_lines(const float* __restrict__ scratch, int lane, f32x16& in) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + j * kLinePitch + 8 * q + 4 * h);
+    in[4 * q + 0] = v[0];
+    in[4 * q + 1] = v[1];
+    in[4 * q + 2] = v[2];
+    in[4 * q + 3] = v[3];
+  }
+}
+
+// operand exchange through LDS: the bf16 part(s) of one input tile, lane-linear 16-byte pieces (conflict-free)
+template <int P>
+__device__ __forceinline__ void put_parts(f32x4* lds, int tile, int lane, const f32x16& v) {
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    Parts<P> x;
+    make_parts<P>(v, hf, x);
+#pragma unroll
+    for (int p = 0; p < P; ++p) lds[((tile * 2 + hf) * P + p) * 64 + lane] = __builtin_bit_cast(f32x4, x.p[p]);
+  }
+}
+template <int P, int IT>
+__device__ __forceinline__ void get_parts(const f32x4* lds, int lane, Parts<P> (&xi)[IT][2]) {
+#pragma unroll
+  for (int t = 0; t < IT; ++t)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int p = 0; p < P; ++p) xi[t][hf].p[p] = __builtin_bit_cast(bf16x8, lds[((t * 2 + hf) * P + p) * 64 + lane]);
+}
+// partial output tiles of the 4 waves: [wave][quad of 4 registers][lane] as 16-byte pieces
+template <int OT>
+__device__ __forceinline__ void put_partial(f32x4* lds, int wave, int lane, const f32x16 (&out)[OT]) {
+#pragma unroll
+  for (int q = 0; q < 4 * OT; ++q) {
+    const f32x4 v = {out[q >> 2][4 * (q & 3) + 0], out[q >> 2][4 * (q & 3) + 1], out[q >> 2][4 * (q & 3) + 2],
+                     out[q >> 2][4 * (q & 3) + 3]};
+    lds[(wave * 4 * OT + q) * 64 + lane] = v;
+  }
+}
+template <int OT>
+__device__ __forceinline__ f32x4 sum_partial(const f32x4* lds, int q, int lane) {      // fixed order: ((w0+w1)+w2)+w3
+  f32x4 v = lds[(0 * 4 * OT + q) * 64 + lane];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const f32x4 a = lds[(w * 4 * OT + q) * 64 + lane];
+    v[0] += a[0];
+    v[1] += a[1];
+    v[2] += a[2];
+    v[3] += a[3];
+  }
+  return v;
+}
+
+// ---- closing MLP, 4 waves per row block: y = W1 relu(W0 x + b0) + b1, dout <= 64 ----------------------------------------
+// Same image, same inputs (incl. the fused scatter) and the same optional kept activations as mlp2_x_kernel.
+template <int P, typename T, int IT, int HT, int OT>
+__global__ __launch_bounds__(256, HT == 4 ? 3 : 2) void mlp2_xs_kernel(GroupTable<gn_mlp2_group_t> Tb, int rows, int dout, int ldy, int N,
+                                                          float divisor) {
+  static_assert(HT % 4 == 0, "hidden tiles are dealt over 4 waves");
+  constexpr int TPW = HT / 4, NA = 2 * IT, NB = 2 * OT, L = TPW * (NA + NB);
+  constexpr int kXin = IT * 2 * P * 64, kPart = 4 * 4 * OT * 64;
+  __shared__ f32x4 lds[kXin > kPart ? kXin : kPart];
+  __shared__ __align__(16) float lines[2][32 * kLinePitch];     // layout change of the fused scatter (waves 0 / 1)
+  const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
+  if (lwg < 0) return;
+  const int gi = find_group(Tb, lwg);
+  const gn_mlp2_group_t G = Tb.g[gi];
+  const int wave = wave_id();
+  const RowBlock rb = row_block(rows, lwg - Tb.first_wg[gi]);
+  const int lane = rb.lane, h = rb.h;
+  const int unit = lwg * 4 + wave;
+  GN_STAMP(unit, 0);
+  GN_STAMP(unit, 8);
+  const float* b0 = G.bias;
+  const float* b1 = G.bias + 32 * HT;
+  const f32x4* img = reinterpret_cast<const f32x4*>(G.Wx) + lane;
+  const f32x4* segA[TPW];
+  const f32x4* segB[TPW];
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int t = wave + 4 * tt;
+    segA[tt] = img + (size_t)pipe_off_A(t, NA, NB) * P * 64;
+    segB[tt] = img + (size_t)pipe_off_B(t, HT, NA, NB) * P * 64;
+  }
+  // consumption order of this wave: A of all its tiles, then B of all its tiles
+  auto at = [&](int s) -> const f32x4* {
+    return s < TPW * NA ? segA[s / NA] + (s % NA) * P * 64 : segB[(s - TPW * NA) / NB] + ((s - TPW * NA) % NB) * P * 64;
+  };
+  PStream<P, L> ps;
+  // fused scatter (IT == 4, waves 0 / 1): accumulated in line layout, handed over through `lines`
+  bool via_lines = false;
+  if constexpr (IT == 4) {
+    if (G.x == nullptr) {
+      if (wave < 2) via_lines = scatter_tile_lines<T>(G, lwg - Tb.first_wg[gi], rows, N, divisor, wave, lane, lines[wave]);
+      else via_lines = G.H != nullptr || G.sym != 0;
+      if (via_lines) __syncthreads();          // (block-uniform: the group's shape decides)
+    }
+  }
+  if (wave < IT) {
+    f32x16 in;
+    if (via_lines && wave < 2) read_tile_lines(lines[wave], lane, in);
+    else mlp2_rows_tile<T>(G, rb.row_ld, h, N, divisor, IT, wave, in);
+    ps.begin(at);       // (behind the gather, whose batches of member rows need the registers; in flight across the exchange)
+    if (G.in_out != nullptr && rb.live) store_tile(G.in_out + (size_t)rb.row * (32 * IT) + 32 * wave + 4 * h, in);
+    put_parts<P>(lds, wave, lane, in);
+  } else {
+    ps.begin(at);
+  }
+  __syncthreads();
+  // layer 1: the input operands are read from LDS one sub-step ahead of their MFMAs (not held in registers: IT = 4
+  // tiles of three parts would be 96 of them, and the launch wants 3 workgroups per CU to run in one round)
+  auto xop = [&](int u, Parts<P>& x) {             // operand of sub-step u of an A phase: input tile u/2, half u%2
+#pragma unroll
+    for (int p = 0; p < P; ++p) x.p[p] = __builtin_bit_cast(bf16x8, lds[(u * P + p) * 64 + lane]);
+  };
+  Parts<P> xa[2];
+  xop(0, xa[0]);
+  GN_STAMP(unit, 1);
+  // accumulators start at zero and the bias tiles — requested before a phase, added behind it — arrive in its shadow
+  // (held from the start they would be live across the gather and cost the third workgroup per CU)
+  f32x16 hid[TPW], bt[TPW];
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    bt[tt] = load_bias_tile(b0 + 32 * (wave + 4 * tt), h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hid[tt][r] = 0.f;
+  }
+  int s = 0;
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      if (s + 1 < TPW * NA) xop((u + 1) % NA, xa[(s + 1) & 1]);
+      ps.step(s, at, xa[s & 1], hid[tt]);
+      ++s;
+    }
+  f32x16 out[OT], bo[OT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o) {
+    if (wave == 0) bo[o] = load_bias_tile(b1 + 32 * o, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[o][r] = 0.f;
+  }
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hid[tt][r] += bt[tt][r];
+    Parts<P> xh[2];
+    if constexpr (P == 1) {
+      make_parts_relu(hid[tt], 0, xh[0]);
+      make_parts_relu(hid[tt], 1, xh[1]);
+    } else {
+      relu16(hid[tt]);
+      if (G.hid_out != nullptr && rb.live)
+        store_tile(G.hid_out + (size_t)rb.row * (32 * HT) + 32 * (wave + 4 * tt) + 4 * h, hid[tt]);
+      make_parts<P>(hid[tt], 0, xh[0]);
+      make_parts<P>(hid[tt], 1, xh[1]);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      ps.step(s, at, xh[u & 1], out[u >> 1]);
+      ++s;
+    }
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[o][r] += bo[o][r];
+  }
+  GN_STAMP(unit, 2);
+  __syncthreads();                                // every wave is past its reads of the exchanged operands
+  put_partial<OT>(lds, wave, lane, out);
+  __syncthreads();
+  GN_STAMP(unit, 3);
+  GN_STAMP(unit, 4);
+  GN_STAMP(unit, 9);
+  if (!rb.live) return;
+  T* yrow = reinterpret_cast<T*>(G.y) + (size_t)rb.row * ldy;
+  const bool vec = ((dout | ldy) & 3) == 0;
+#pragma unroll
+  for (int qq = 0; qq < OT; ++qq) {               // wave w finishes quads [w*OT, w*OT + OT) of the 4*OT
+    const int q = wave * OT + qq;
+    const f32x4 v = sum_partial<OT>(lds, q, lane);
+    const int f = 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+    if (vec) {
+      if (f < dout) st4(yrow + f, v);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (f + c < dout) st1(yrow + f + c, v[c]);
+    }
+  }
+}
+
 }  // namespace

@@ -1095,9 +1095,33 @@ extern "C" int gn_node_linear_f32(const float* x, const float* W, const float* b
 template <int P, typename T>
 static int mlp2_x_launch(GroupTable<gn_mlp2_group_t>& T_, int n_groups, int rows, int din, int dh, int dout, int ldy,
                          int N, float divisor, hipStream_t s) {
+  const int OT = (dout + 31) / 32;
+  // a small launch: 4 waves per row block (mlp2_xs_kernel; its fused scatter reads every hyperedge of the scene, so
+  // hyper groups need E <= 16).  GN_MLP2_XS = 0 / 1 forces the choice (parity tests run both)
+  const int blocks32 = (rows + 31) / 32;
+  bool xs = (long long)blocks32 * n_groups <= 1536;
+  if (const char* e = getenv("GN_MLP2_XS")) xs = atoi(e) != 0;
+  for (int g = 0; g < n_groups; ++g)
+    if (T_.g[g].x == nullptr && T_.g[g].H != nullptr && T_.g[g].E > 16) xs = false;
+  if (xs) {
+    for (int g = 0; g <= n_groups; ++g) T_.first_wg[g] = g * blocks32;
+    const dim3 grid(table_xcd_grid(T_)), block(256);
+#define GN_MLP2XS(IT, HT, OTv) \
+  hipLaunchKernelGGL((mlp2_xs_kernel<P, T, IT, HT, OTv>), grid, block, 0, s, T_, rows, dout, ldy, N, divisor)
+    if (din == 64 && dh == 128 && OT == 1) GN_MLP2XS(2, 4, 1);
+    else if (din == 64 && dh == 128) GN_MLP2XS(2, 4, 2);
+    else if (din == 128 && dh == 128 && OT == 1) GN_MLP2XS(4, 4, 1);
+    else if (din == 128 && dh == 128) GN_MLP2XS(4, 4, 2);
+    else if (din == 64 && dh == 256 && OT == 1) GN_MLP2XS(2, 8, 1);
+    else if (din == 64 && dh == 256) GN_MLP2XS(2, 8, 2);
+    else if (din == 128 && dh == 256 && OT == 1) GN_MLP2XS(4, 8, 1);
+    else if (din == 128 && dh == 256) GN_MLP2XS(4, 8, 2);
+    else return GN_ERR_SHAPE;
+#undef GN_MLP2XS
+    return gn_check_launch();
+  }
   for (int g = 0; g <= n_groups; ++g) T_.first_wg[g] = g * row_grid(rows);
   const dim3 grid(table_xcd_grid(T_)), block(256);
-  const int OT = (dout + 31) / 32;
 #define GN_MLP2X(IT, HT, OTv) \
   hipLaunchKernelGGL((mlp2_x_kernel<P, T, IT, HT, OTv>), grid, block, 0, s, T_, rows, dout, ldy, N, divisor)
   if (din == 64 && dh == 128 && OT == 1) GN_MLP2X(2, 4, 1);

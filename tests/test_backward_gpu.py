@@ -247,13 +247,17 @@ def test_graphed_train_step_matches_eager_and_learns():
     assert float(((out_now - tgt) ** 2).mean()) < l0
 
 
+@pytest.mark.parametrize("xs", ["1", "0"])
 @pytest.mark.parametrize("name", ["n11_b5", "n7_b3_nmp2"])
-def test_hip_backward_matches_reference_gradients(name):
+def test_hip_backward_matches_reference_gradients(name, xs, monkeypatch):
     """The HIP backward against gradients produced by the REFERENCE's own autograd
     (tests/golden/grad_*.npz, generated by make_golden_backward.py): same weights (golden state_dicts), same
     inputs, same uniforms, same loss.  dL/dh and the stored parameter gradients element-wise, every parameter
     gradient through its (sum, sum|.|, max|.|).  Gate: 1e-4 of max|g| when no scene of the golden batch holds a ReLU
-    unit inside the rounding window of zero (relu_probe.py), else 2e-3; the measured errors are printed."""
+    unit inside the rounding window of zero (relu_probe.py), else 2e-3; the measured errors are printed.
+    xs: the forward's closing MLP (which also WRITES the activations the backward reads) through the
+    4-waves-per-row-block kernel ("1", the launcher's choice at this size) and the one-wave-per-block kernel ("0")."""
+    monkeypatch.setenv("GN_MLP2_XS", xs)
     import numpy as np
     import os
     import groupnet_amd as G

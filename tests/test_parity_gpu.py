@@ -53,8 +53,12 @@ def loaded_modules(case):
 # ---------------------------------------------------------------------------------------------
 # golden vectors of the reference
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("xs", ["1", "0"])
 @pytest.mark.parametrize("name", case_names())
-def test_modules_match_reference_goldens(name):
+def test_modules_match_reference_goldens(name, xs, monkeypatch):
+    """xs: the closing MLP (with its fused scatter) through its 4-waves-per-row-block kernel ("1", what the launcher picks
+    at these sizes) and through the one-wave-per-row-block kernel ("0", what it picks for large launches)."""
+    monkeypatch.setenv("GN_MLP2_XS", xs)
     c = load_case(name)
     pair, hyper, sp, sh, nmp = loaded_modules(name)
     h, corr = to_dev(c["h"]), to_dev(c["corr"])
@@ -1036,3 +1040,29 @@ def test_fused_node2edge_pooling_equals_the_node2edge_launch(monkeypatch):
         print(f"\nfused pooling ({tag}) vs node2edge launch: max rel diff {err:.2e}")
         assert err <= 1e-6 and torch.equal(outs[tag][1], ref[1])
     assert float((fac_f - fac_u).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,scales,nmp", [(7, 11, [2, 5, 11], 1), (3, 6, [2, 6], 2), (33, 5, [3], 1)])
+def test_mlp2_xs_kernel_equals_the_one_wave_per_block_kernel(B, N, scales, nmp, dtype, monkeypatch):
+    """mlp2_xs_kernel (4 waves share a row block: hidden tiles dealt over the waves, partial sums through LDS; fused
+    scatter accumulated in line layout) against mlp2_x_kernel on the same block, inputs and uniforms — pairwise and hyper
+    groups, the plain-input form (nmp_layers = 2: the MLP between the rounds), ragged last row block: identical
+    incidence, features equal up to the summation order of the four partial sums (fp32: 2e-6 relative; bf16 storage:
+    one rounding of the stored result, 1.6e-2)."""
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    torch.manual_seed(5)
+    blk = MultiScaleHGNN(scales, nmp_layers=nmp).to(dev()).eval()
+    f = torch.randn(B, N, 64, device=dev()).to(dtype)
+    U = [[torch.rand(s, device=dev()) for _ in range(nmp)] for s in blk.noise_shapes(B, N)]
+    outs = {}
+    with torch.no_grad():
+        for xs in ("0", "1"):
+                    monkeypatch.setenv("GN_MLP2_XS", xs)
+            outs[xs] = blk(f, noise_u=U)
+    a, b = outs["0"][0].float(), outs["1"][0].float()
+    err = float((a - b).abs().max()) / max(1.0, float(a.abs().max()))
+    print(f"\nmlp2 xs vs one-wave-per-block kernel ({dtype}, B={B} N={N} nmp={nmp}): max rel diff {err:.2e}")
+    assert torch.equal(outs["0"][1], outs["1"][1])
+    assert torch.isfinite(b).all()
+    assert err <= (2e-6 if dtype == torch.float32 else 1.6e-2)

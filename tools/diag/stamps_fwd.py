@@ -56,12 +56,18 @@ def wrap(name, n_units_fn, groups_fn=None):
         return r
     setattr(ops, name, w)
 
-wrap("node_stage_grouped", lambda items, keep, specs: 8192 if B > 512 else 704 + 528, (lambda *a: None) if B > 512 else (lambda *a: [("chain", slice(0, 704)), ("A", slice(704, 1232))]))
+NCH = 704
+wrap("node_stage_grouped", lambda items, keep, specs: 8192 if B > 512 else NCH + 528, (lambda *a: None) if B > 512 else (lambda *a: [("chain", slice(0, NCH)), ("A", slice(NCH, NCH + 528))]))
+def edge_rows(e):
+    if isinstance(e, ops.PoolSpec):       # rows formed inside the kernel: unordered pairs / hyperedges
+        Bn, Nn = e.xp.shape[0], e.xp.shape[1]
+        return Bn * (Nn * (Nn + 1) // 2 if e.H is None else e.H.shape[1])
+    return e.shape[0] * e.shape[1]
 def edge_units(items, *a, **k):
-    return sum(((it[0].shape[0] * it[0].shape[1] + 127) // 128) * 4 for it in items)
+    return sum(((edge_rows(it[0]) + 127) // 128) * 4 for it in items)
 wrap("edge_mlp_gumbel_grouped", (lambda *a, **k: 8192) if B > 512 else edge_units, (lambda *a, **k: None) if B > 512 else (lambda items, *a, **k: [("pair", slice(0, 1056)), ("hyper", slice(1056, 1056 + 400))]))
 wrap("agg_mlp_grouped", lambda items: 8192 if B > 512 else 4 * 700, (lambda items: None) if B > 512 else (lambda items: [("hyperA", slice(0, 352)), ("hyperB", slice(352, 704)), ("pair", slice(704, 1760)), ("small", slice(1760, 1824))]))
-wrap("mlp2_grouped", lambda items, keep=None: 8192 if B > 512 else 4 * 44 * 4, None)
+wrap("mlp2_grouped", lambda items, keep=None: 8192 if B > 512 else (4 * 176 * 4 if os.environ.get("GN_MLP2_XS", "1") != "0" else 4 * 44 * 4), None)
 M.ops = ops
 with torch.no_grad():
     G.set_noise_mode("device", seed=3)
