@@ -140,13 +140,16 @@ __device__ __forceinline__ void gumbel_softmax_row(const f32x16& lg, const float
   float y[8];
   float m = -INFINITY;
   const bool hi = K > 8;
+  // FAST: one reciprocal per row instead of a division per element (an IEEE division is ~10 instructions; with 12-16 of
+  // them per row the bf16-storage edge kernel spent as many issue slots dividing as on its matrix work)
+  const float inv_tau = 1.f / tau;
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     if (g == 0 || hi) {
 #pragma unroll
       for (int r = 4 * g; r < 4 * g + 4; ++r) {
         const float gg = FAST ? -__logf(eps - __logf(u[r] + eps)) : -logf(eps - logf(u[r] + eps));
-        y[r] = (lg[r] + gg) / tau;
+        y[r] = FAST ? (lg[r] + gg) * inv_tau : (lg[r] + gg) / tau;
         if (feat_of(r, h) < K) m = fmaxf(m, y[r]);
       }
     } else {
@@ -170,8 +173,13 @@ __device__ __forceinline__ void gumbel_softmax_row(const f32x16& lg, const float
     }
   }
   s += __shfl_xor(s, 32, GN_WAVE);
+  const float inv_s = 1.f / s;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) d[r] = d[r] / s;
+  for (int g = 0; g < 2; ++g)
+    if (g == 0 || hi) {                     // (the dead half stays 0: 0 / s with s >= 1)
+#pragma unroll
+      for (int r = 4 * g; r < 4 * g + 4; ++r) d[r] = FAST ? d[r] * inv_s : d[r] / s;
+    }
 }
 
 // uniforms of this lane's features for ordered row `orow`: from U, or from the Philox stream.  A lane's features come

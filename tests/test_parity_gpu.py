@@ -1058,7 +1058,7 @@ def test_mlp2_xs_kernel_equals_the_one_wave_per_block_kernel(B, N, scales, nmp, 
     outs = {}
     with torch.no_grad():
         for xs in ("0", "1"):
-                    monkeypatch.setenv("GN_MLP2_XS", xs)
+            monkeypatch.setenv("GN_MLP2_XS", xs)
             outs[xs] = blk(f, noise_u=U)
     a, b = outs["0"][0].float(), outs["1"][0].float()
     err = float((a - b).abs().max()) / max(1.0, float(a.abs().max()))
