@@ -195,6 +195,35 @@ __device__ __forceinline__ void fetch_uniforms(const float* __restrict__ U, unsi
     }
     return;
   }
+  {
+    // K <= 8: the row's K consecutive stream positions lie in at most three Philox blocks, in two whenever
+    // (first position mod 4) + K <= 8 (always for the pairwise module's K = 6: its rows start at even positions).  Then
+    // the row's two lanes evaluate ONE block each and swap: a Philox block is ten rounds of quarter-rate 32x32->64
+    // multiplies, the most expensive piece of the epilogue, and each lane evaluating the block(s) of its own features
+    // made the wave pay two evaluations per row and ordered edge.
+    const unsigned long long pos_row = base + (unsigned long long)orow * K;
+    const int o = (int)(pos_row & 3ull);
+    if (K <= 8 && o + K <= 8) {                             // (same answer in both lanes of a row)
+      uint32_t c[4], w[8];
+      gn_philox_block((pos_row >> 2) + (unsigned long long)h, seed, c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)c[i], 32, GN_WAVE);
+        w[i] = h ? other : c[i];
+        w[4 + i] = h ? c[i] : other;
+      }
+      const int k0 = o + 4 * h;                             // word of this lane's first feature
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + j;
+        const uint32_t lo = (k & 2) ? ((k & 1) ? w[3] : w[2]) : ((k & 1) ? w[1] : w[0]);
+        const uint32_t hi = (k & 2) ? ((k & 1) ? w[7] : w[6]) : ((k & 1) ? w[5] : w[4]);
+        u[j] = 4 * h + j < K ? gn_philox_to_uniform((k & 4) ? hi : lo) : 0.5f;
+        u[4 + j] = 0.5f;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const int f0 = 8 * g + 4 * h;                           // feat_of(4 g, h)
