@@ -397,7 +397,12 @@ struct NodeTable {
   int n, rows, wgs_per_group, chain_wgs;
   XcdSections xs;                   // sections: every group's chain, then every (group, output-tile chunk) of WA
 };
-constexpr int kATiles = 8;   // output tiles of WA per A workgroup
+// output tiles of WA per "A" workgroup (a multiple of 4).  4: 264 workgroups of 16 sub-steps at B = 512 instead of 132 of
+// 32 — the A workgroups were the node stage's last to finish (same-session A/B: launch 22.1 -> 19.9 us).
+#ifndef GN_KATILES
+#define GN_KATILES 4
+#endif
+constexpr int kATiles = GN_KATILES;
 
 template <int P, typename T>
 __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
