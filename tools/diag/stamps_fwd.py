@@ -57,7 +57,7 @@ def wrap(name, n_units_fn, groups_fn=None):
     setattr(ops, name, w)
 
 NCH = 704
-wrap("node_stage_grouped", lambda items, keep, specs: 8192 if B > 512 else NCH + 528, (lambda *a: None) if B > 512 else (lambda *a: [("chain", slice(0, NCH)), ("A", slice(NCH, NCH + 528))]))
+wrap("node_stage_grouped", lambda items, keep, specs: 8192 if B > 512 else NCH + 1056, (lambda *a: None) if B > 512 else (lambda *a: [("chain", slice(0, NCH)), ("A", slice(NCH, NCH + 1056))]))
 def edge_rows(e):
     if isinstance(e, ops.PoolSpec):       # rows formed inside the kernel: unordered pairs / hyperedges
         Bn, Nn = e.xp.shape[0], e.xp.shape[1]
