@@ -1332,8 +1332,10 @@ __global__ __launch_bounds__(256, 2) void edge_rb2_kernel(GroupTable<gn_edge_gro
 // ---- A6 / closing MLP on the bf16 cores: y = W1 relu(W0 x + b0) + b1, dout <= 64 ---------------------------------
 // Image, hidden-tile-major: per hidden tile t the tiles [W0(t, in 0..IT-1), W1(0..OT-1, t)].  Input rows read from
 // x or formed on the fly (fused scatter, IT == 4) exactly as in mlp2_kernel.
+// (occupancy: the fused scatter of the three-part kernel keeps ~200 registers in flight — one workgroup per CU; the
+// bf16-storage kernel fits two with 128 inputs, three with 64)
 template <int P, typename T, int IT, int HT, int OT>
-__global__ __launch_bounds__(256, IT == 4 ? 1 : 2) void mlp2_x_kernel(GroupTable<gn_mlp2_group_t> Tb, int rows, int dout, int ldy,
+__global__ __launch_bounds__(256, P == 1 ? (IT == 4 ? 2 : 3) : (IT == 4 ? 1 : 2)) void mlp2_x_kernel(GroupTable<gn_mlp2_group_t> Tb, int rows, int dout, int ldy,
                                                         int N, float divisor) {
   using WS = WStream<P>;
   __shared__ f32x4 wring[WS::kRingF4];

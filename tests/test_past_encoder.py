@@ -9,6 +9,18 @@ import torch
 from oracle import ms_hgnn_oracle as O
 from oracle import past_encoder_oracle as PO
 
+def close_to(got, want, tag, rel=1e-5):
+    """north_star's bar is 1e-5 ABSOLUTE on O(1) features.  The encoders' outputs are un-normalised (max|value| 200 .. 800 on
+    these inputs: the fp32 spacing there is 1.5e-5 .. 6e-5, so 1e-5 absolute is below one ulp), so the gate is
+    1e-5 * max(1, max|want|); the absolute error and the scale are printed (measured on MI355X: 0.9e-4 .. 4.8e-4 absolute
+    = 4e-7 .. 1e-6 of the scale, a handful of ulps)."""
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    err, scale = float((got - want).abs().max()), float(want.abs().max())
+    print(f"\n{tag}: max abs err {err:.2e} at max|want| {scale:.2f} -> {err / max(1.0, scale):.2e} of scale "
+          f"({'meets' if err <= 1e-5 else 'above'} 1e-5 absolute)")
+    assert err <= rel * max(1.0, scale), tag
+
+
 
 def make(scales, seed=0):
     from groupnet_amd.past_encoder import PastEncoder
@@ -72,8 +84,7 @@ def test_past_encoder_matches_oracle(scales):
     with torch.no_grad():
         out, new_H = enc(x.to(dev), B, N)
     assert out.shape == want.shape
-    scale = float(want.abs().max())
-    assert float((out.cpu() - want).abs().max()) <= 1e-5 * max(1.0, scale)
+    close_to(out, want, f"PastEncoder vs oracle, scales {scales}")
     if len(scales) > 1:
         # H is built from the kernel's own affinity; these seeded inputs have well-separated neighbours
         assert torch.equal(new_H.cpu(), torch.cat(Hs, dim=1))
@@ -133,7 +144,7 @@ def test_future_encoder_matches_oracle(scales):
     with torch.no_grad():
         got = enc(x.to(dev), B, N, past.to(dev))
     assert got.shape == (B * N, 64)
-    assert float((got.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    close_to(got, want, "encoder output")
 
 
 @pytest.mark.gpu
@@ -168,19 +179,24 @@ def test_encoder_training_gradients(which):
         out = enc(x.to(dev), B, N)[0] if which == "past" else enc(x.to(dev), B, N, past.to(dev))
     finally:
         M._draw_uniform = orig
-    assert float((out.detach().cpu() - want.detach()).abs().max()) <= 1e-5 * max(1.0, float(want.detach().abs().max()))
+    close_to(out, want, f"{which} encoder (training mode) vs oracle")
     (out * R.to(dev)).sum().backward()
     used = [k for k, v in state.items() if v.grad is not None and float(v.grad.abs().max()) > 0]
     assert "input_fc.weight" in used and "pos_encoder.fc.weight" in used
     hip = dict(enc.named_parameters())
     gmax = max(float(state[k].grad.abs().max()) for k in used)
+    worst = 0.0
     for k in used:
         a, b = hip[k].grad, state[k].grad
         assert a is not None, k
         # relative to the parameter's own gradient, floored at 1 % of the largest gradient in the model: some
         # directions (the attention bias under a full softmax) have an exactly-zero gradient and only carry noise
         scale = max(float(b.abs().max()), 1e-2 * gmax)
+        worst = max(worst, float((a.cpu() - b).abs().max()) / scale)
         assert float((a.cpu() - b).abs().max()) / scale <= 2e-3, k
+    # (2e-3: dropout-free but not ReLU-clean batches — a unit within rounding of zero may be on in one forward and off in
+    # the other, tests/relu_probe.py; the module-level backward tests gate their clean scenes at 2e-5)
+    print(f"\n{which} encoder gradients vs torch autograd on the oracle: worst parameter {worst:.2e} of its scale (gate 2e-3)")
 
 
 # ---- pinned by the reference itself: goldens from tests/golden/make_golden_past_encoder.py --------------------
@@ -225,7 +241,7 @@ def test_past_encoder_matches_reference_goldens(name):
     with torch.no_grad():
         out, new_H = enc(torch.from_numpy(c["x"]).to(dev), B, 11)
     want = torch.from_numpy(c["output_feature"])
-    assert float((out.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    close_to(out, want, f"PastEncoder vs reference golden {name}")
     assert torch.equal(new_H.cpu(), torch.from_numpy(c["new_H"]))
 
 
@@ -263,7 +279,7 @@ def test_future_encoder_matches_reference_golden():
     with torch.no_grad():
         got = enc(torch.from_numpy(c["x"]).to(dev), B, 11, torch.from_numpy(c["past"]).to(dev))
     want = torch.from_numpy(c["q_z_params"])
-    assert float((got.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    close_to(got, want, "encoder output")
 
 
 @pytest.mark.gpu
@@ -282,7 +298,7 @@ def test_past_encoder_training_mode_matches_reference_golden():
     out, new_H = enc(torch.from_numpy(c["x"]).to(dev), B, 11)
     assert out.requires_grad
     want = torch.from_numpy(c["output_feature"])
-    assert float((out.detach().cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    close_to(out, want, "training-mode golden")
     assert torch.equal(new_H.cpu(), torch.from_numpy(c["new_H"]))
 
 
