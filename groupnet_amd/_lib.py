@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -69,6 +69,10 @@ class PackSeg(ctypes.Structure):       # gn_pack_seg_t
                 ("IT", _I), ("scale", _F), ("dst_ld", _I)]
 
 
+class SplitJob(ctypes.Structure):      # gn_split_job_t
+    _fields_ = [("packed", _P), ("out", _P), ("n_tiles", _I), ("reserved", _I)]
+
+
 class GemmDesc(ctypes.Structure):      # gn_gemm_desc_t
     _fields_ = [("A", _P), ("B", _P), ("C", _P), ("bias", _P), ("mask", _P), ("rs", _P), ("colsum", _P),
                 ("M", _I), ("N", _I), ("K", _I), ("lda", _I), ("ldb", _I), ("ldc", _I), ("ldmask", _I), ("rs_ld", _I),
@@ -92,6 +96,7 @@ SIGNATURES = {
     "gn_packed_elems": (_SZ, [_I, _I]),
     "gn_pack_linear_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "gn_split_bf16_f32": (_I, [_P, _P, _I, _I, _P]),
+    "gn_split_bf16_batch_f32": (_I, [_P, _I, _I, _I, _P]),
     "gn_pack_segments_f32": (_I, [_P, _I, _I, _P]),
     "gn_node_mlp_f32": (_I, [ctypes.POINTER(NodeGroup), _I, _I, _P]),
     "gn_node_mlp_bf16": (_I, [ctypes.POINTER(NodeGroup), _I, _I, _P]),

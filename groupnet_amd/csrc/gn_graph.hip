@@ -858,7 +858,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) 
 
 }  // namespace
 
-extern "C" int gn_abi_version(void) { return 27; }
+extern "C" int gn_abi_version(void) { return 28; }
 
 extern "C" const char* gn_strerror(int code) {
   switch (code) {

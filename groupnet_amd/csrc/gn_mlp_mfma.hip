@@ -69,9 +69,19 @@ __global__ __launch_bounds__(256) void pack_segments_kernel(const gn_pack_seg_t*
   }
 }
 
+// one thread per (tile, half, lane, j) of one image; the batch kernel serves one image per blockIdx.y
+__device__ __forceinline__ void split_bf16_image(const float* __restrict__ packed, __bf16* __restrict__ out, int n_tiles,
+                                                 int parts);
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ packed, __bf16* __restrict__ out,
                                                          int n_tiles, int parts) {
-  // one thread per (tile, half, lane, j)
+  split_bf16_image(packed, out, n_tiles, parts);
+}
+__global__ __launch_bounds__(256) void split_bf16_batch_kernel(const gn_split_job_t* __restrict__ jobs, int parts) {
+  const gn_split_job_t J = jobs[blockIdx.y];
+  split_bf16_image(J.packed, reinterpret_cast<__bf16*>(J.out), J.n_tiles, parts);
+}
+__device__ __forceinline__ void split_bf16_image(const float* __restrict__ packed, __bf16* __restrict__ out, int n_tiles,
+                                                 int parts) {
   const long long total = (long long)n_tiles * 2 * 64 * 8;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63), half = (int)((idx >> 9) & 1);
@@ -824,6 +834,16 @@ extern "C" int gn_split_bf16_f32(const float* packed, void* out, int n_tiles, in
   const long long total = (long long)n_tiles * 1024;
   hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)),
                      dim3(256), 0, (hipStream_t)stream, packed, reinterpret_cast<__bf16*>(out), n_tiles, parts);
+  return gn_check_launch();
+}
+
+extern "C" int gn_split_bf16_batch_f32(const gn_split_job_t* jobs_dev, int n_jobs, int max_tiles, int parts,
+                                       gn_stream_t stream) {
+  GN_REQUIRE_PTR(jobs_dev);
+  if (n_jobs < 1 || n_jobs > 65535 || max_tiles < 1 || (parts != 1 && parts != 3)) return GN_ERR_SHAPE;
+  const long long total = (long long)max_tiles * 1024;
+  const unsigned gx = (unsigned)((total + 255) / 256 < 256 ? (total + 255) / 256 : 256);
+  hipLaunchKernelGGL(split_bf16_batch_kernel, dim3(gx, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, parts);
   return gn_check_launch();
 }
 

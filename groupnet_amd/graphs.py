@@ -16,6 +16,7 @@ from typing import Callable, Optional, Sequence, Tuple
 import torch
 
 from . import MS_HGNN_batch as _mods
+from . import ops
 from .multiscale import MultiScaleHGNN
 
 Tensor = torch.Tensor
@@ -151,6 +152,7 @@ class GraphedTrainStep:
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.draws_per_step = sum(b * e * k for (b, e, k) in block.noise_shapes(B, N)) * block.interaction.nmp_layers
         self.graph = torch.cuda.CUDAGraph()
+        self._repack: dict = {}
         prev = (_mods._NoiseState.mode, _mods._NoiseState.seed, _mods._NoiseState.offset, _mods._NoiseState.counter)
         try:
             with torch.cuda.device(self.device):
@@ -173,10 +175,13 @@ class GraphedTrainStep:
     def _step(self) -> Tensor:
         _mods.set_noise_mode("device", seed=self.seed, offset=0, counter=self.counter)
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.enable_grad():
-            out, H = self.block(self.f_in, advance=(self.counter, self.draws_per_step))
-            loss = self.loss_fn(out, H, *self.targets)
-        loss.backward()
+        # every packed weight image of the step from TWO launches at its head (ops.repack_scope: the first warm-up step
+        # records which plans / images a step touches)
+        with ops.repack_scope(self._repack):
+            with torch.enable_grad():
+                out, H = self.block(self.f_in, advance=(self.counter, self.draws_per_step))
+                loss = self.loss_fn(out, H, *self.targets)
+            loss.backward()
         self.optimizer.step()
         return loss.detach()
 

@@ -382,9 +382,91 @@ class PackPlan:
 
     def refresh(self) -> None:
         # (segments always write the same positions: the padding zeroed in finish() stays zero)
+        if _REPACK["rec"] is not None:
+            _REPACK["rec"][0].append(self)
+        elif _REPACK["done_plans"] is not None and id(self) in _REPACK["done_plans"]:
+            return      # this step's RepackBatch refreshed it already
         with torch.cuda.device(self.device):
             check(load().gn_pack_segments_f32(_ptr(self.table), len(self._segs), self.max_elems, stream_handle()),
                   "gn_pack_segments_f32")
+
+
+# ---- one re-pack per training step -----------------------------------------------------------------------------
+# A training step re-derives every packed weight image from the parameters (the optimizer just rewrote them): one
+# `refresh` launch per pack plan and one `split_bf16` launch per bf16-core image — 21 + 17 launches of ~4.6 us per step
+# of the multiscale block, 9 % of the graphed step.  All of them read only the parameters, so they can run first and
+# together: `repack_scope` RECORDS which plans / images one step touches (first use), then runs them as TWO launches —
+# `gn_pack_segments_f32` over the concatenated segment tables, `gn_split_bf16_batch_f32` over all images — at the head
+# of every later step and turns the recorded per-plan / per-image launches of that step into no-ops.  A plan or image
+# that is not in the batch (rebuilt because parameter storage moved) simply takes its own launch as before.
+_REPACK = {"rec": None, "done_plans": None, "done_splits": None}
+
+
+class RepackBatch:
+    def __init__(self, plans: Sequence["PackPlan"], splits: Sequence[Tuple[Tensor, Tensor, int]]):
+        self.plans, self.splits = list(plans), list(splits)          # (keeps arenas, tables and images alive)
+        dev = self.plans[0].device
+        self.device = dev
+        self.table = torch.cat([p.table for p in self.plans])
+        self.n_segs = sum(len(p._segs) for p in self.plans)
+        self.max_elems = max(p.max_elems for p in self.plans)
+        if self.n_segs > 65535:
+            raise ValueError("RepackBatch: too many segments for one launch")
+        self.parts = sorted({pt for _, _, pt in self.splits})
+        self.jobs = {}
+        for pt in self.parts:
+            js = [(a, b) for a, b, q in self.splits if q == pt]
+            arr = (_lib.SplitJob * len(js))()
+            for i, (a, b) in enumerate(js):
+                arr[i] = _lib.SplitJob(a.data_ptr(), b.data_ptr(), a.numel() // 1024, 0)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self.jobs[pt] = (raw, len(js), max(a.numel() // 1024 for a, _ in js))
+        self.plan_ids = {id(p) for p in self.plans}
+        self.split_keys = {(a.data_ptr(), b.data_ptr(), q) for a, b, q in self.splits}
+
+    def run(self) -> None:
+        with torch.cuda.device(self.device):
+            check(load().gn_pack_segments_f32(_ptr(self.table), self.n_segs, self.max_elems, stream_handle()),
+                  "gn_pack_segments_f32")
+            for pt, (raw, n, mx) in self.jobs.items():
+                check(load().gn_split_bf16_batch_f32(_ptr(raw), n, mx, pt, stream_handle()), "gn_split_bf16_batch_f32")
+
+
+class repack_scope:
+    """``with repack_scope(holder):`` around ONE whole training step (forward and backward).  `holder` is a dict owned by
+    the caller; its first use records, later uses replay the batch (see above).  Not re-entrant."""
+
+    def __init__(self, holder: dict):
+        self.h = holder
+
+    def __enter__(self):
+        if _REPACK["rec"] is not None or _REPACK["done_plans"] is not None:
+            raise RuntimeError("repack_scope is not re-entrant")
+        batch = self.h.get("batch")
+        if batch is None:
+            _REPACK["rec"] = ([], [])
+        else:
+            batch.run()
+            _REPACK["done_plans"], _REPACK["done_splits"] = batch.plan_ids, batch.split_keys
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rec = _REPACK["rec"]
+        _REPACK["rec"] = _REPACK["done_plans"] = _REPACK["done_splits"] = None
+        if rec is not None and et is None:
+            plans, seen = [], set()
+            for p in rec[0]:
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    plans.append(p)
+            splits, seen2 = [], set()
+            for a, b, q in rec[1]:
+                k = (a.data_ptr(), b.data_ptr(), q)
+                if k not in seen2:
+                    seen2.add(k)
+                    splits.append((a, b, q))
+            self.h["batch"] = RepackBatch(plans, splits) if plans else None
+        return False
 
 
 def pipeline_order(HT: int) -> List[Tuple[str, int]]:
@@ -685,6 +767,10 @@ def split_bf16(packed: Tensor, out: Optional[Tensor] = None, parts: int = 3) -> 
     n_tiles = packed.numel() // 1024
     if out is None:
         out = torch.empty(n_tiles * 2 * parts * 64 * 8, dtype=torch.int16, device=packed.device)
+    if _REPACK["rec"] is not None:
+        _REPACK["rec"][1].append((packed, out, int(parts)))
+    elif _REPACK["done_splits"] is not None and (packed.data_ptr(), out.data_ptr(), int(parts)) in _REPACK["done_splits"]:
+        return out      # this step's RepackBatch built it already
     with torch.cuda.device(packed.device):
         check(load().gn_split_bf16_f32(_ptr(packed), ctypes.c_void_p(out.data_ptr()), n_tiles, int(parts),
                                        stream_handle()), "gn_split_bf16_f32")

@@ -325,6 +325,18 @@ int gn_agg_mlp_bf16(const gn_agg_group_t* groups, int n_groups, gn_stream_t stre
  * order in which a lane's accumulator registers hold those features.  parts = 3: x = p1 + p2 + p3 (8 mantissa
  * bits each, round to nearest: the fp32-accurate path); parts = 1: p1 = x rounded to bf16 (the bf16 twins). */
 int gn_split_bf16_f32(const float* packed, void* out, int n_tiles, int parts, gn_stream_t stream);
+/* The same for `n_jobs` images in ONE launch (job table in DEVICE memory; max_tiles = the largest n_tiles): what a
+ * training step needs after its optimizer update — every weight image of every module, one launch after the one
+ * gn_pack_segments_f32 launch over the concatenated segment tables — instead of one launch per image (38 launches
+ * of ~4 us each per step of the multiscale block; the reference re-reads its nn.Parameters directly,
+ * train_hyper_nba.py:107-118). */
+typedef struct {
+  const float* packed;
+  void* out;
+  int n_tiles;
+  int reserved;
+} gn_split_job_t;
+int gn_split_bf16_batch_f32(const gn_split_job_t* jobs, int n_jobs, int max_tiles, int parts, gn_stream_t stream);
 
 /* ---- A5, pairwise graph, layer 1 hoisted to the nodes -----------------------------------------
  * For the pairwise graph the typed MLP's input row is eo = ori_i + ori_j, so its first layer is

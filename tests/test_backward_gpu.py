@@ -1,5 +1,7 @@
 """Backward of the modules: gradients of the HIP path (fused forward + HIP backward
 through torch.autograd) against torch autograd on the CPU oracle, same weights, same inputs, same noise."""
+import contextlib
+
 import pytest
 import torch
 
@@ -536,3 +538,63 @@ def test_seeded_training_forward_sees_the_noise_of_the_seeded_inference_forward(
     b, _ = blk.train()(f)                    # parameters require grad: the autograd path
     assert b.requires_grad
     assert float((a - b.detach()).abs().max()) <= 1e-6
+
+
+def test_repack_scope_two_launches_equal_the_per_plan_refreshes():
+    """ops.repack_scope (what GraphedTrainStep wraps every step in): the first step records the pack plans / bf16-core
+    images a training step touches, later steps rebuild ALL of them with two launches up front and skip the recorded
+    per-plan launches.  Two blocks with identical weights take the same three SGD steps (the second and third step see
+    parameters rewritten through `.data`, the case the per-step refresh exists for) — one inside the scope, one without:
+    identical losses and parameters, bit for bit, and the scoped block's later steps really were served by the batch."""
+    import copy
+    from groupnet_amd import ops
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    import groupnet_amd as G
+    dev = lambda: torch.device("cuda:0")
+    torch.manual_seed(31)
+    a = MultiScaleHGNN([2, 5]).to(dev()).train()
+    b = copy.deepcopy(a)
+    B, N = 6, 7
+    f = torch.randn(B, N, 64, device=dev())
+    tgt = torch.randn(B, N, a.out_features, device=dev())
+    U = [[torch.rand(s, device=dev())] for s in a.noise_shapes(B, N)]
+    holder = {}
+    calls = {"pack": 0}
+    orig = ops.PackPlan.refresh
+
+    def counting(self):
+        before = ops._REPACK["done_plans"]
+        if not (before is not None and id(self) in before):
+            calls["pack"] += 1
+        return orig(self)
+
+    losses = {"a": [], "b": []}
+    ops.PackPlan.refresh = counting
+    try:
+        for step in range(3):
+            for name, blk in (("a", a), ("b", b)):
+                ctx = ops.repack_scope(holder) if name == "a" else contextlib.nullcontext()
+                calls["pack"] = 0
+                with ctx:
+                    out, _ = blk(f, noise_u=U)
+                    loss = ((out - tgt) ** 2).mean()
+                    blk.zero_grad(set_to_none=True)
+                    loss.backward()
+                if name == "a" and step > 0:
+                    assert calls["pack"] == 0, "a recorded plan took its own refresh launch"
+                if name == "b":
+                    assert calls["pack"] > 0
+                with torch.no_grad():
+                    for p in blk.parameters():
+                        if p.grad is not None:
+                            p.data.add_(p.grad, alpha=-0.05)       # behind autograd's back: no version bump
+                losses[name].append(float(loss.detach()))
+    finally:
+        ops.PackPlan.refresh = orig
+    assert holder.get("batch") is not None and len(holder["batch"].plans) > 4
+    print(f"\nrepack_scope: {len(holder['batch'].plans)} plans / {len(holder['batch'].splits)} images per step in two launches; "
+          f"losses {losses['a']}")
+    assert losses["a"] == losses["b"]
+    assert losses["a"][2] != losses["a"][0]
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
