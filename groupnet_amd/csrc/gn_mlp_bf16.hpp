@@ -858,10 +858,15 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
     // A_t = tile t of layer 1 (4 sub-steps), ReLU * ef_k, its bf16 part(s), B_t = its contribution to both output
     // tiles (4 sub-steps)) — one hidden tile live --------------------------------------------------------------
     f32x16 in[2];
-    if (G.eo != nullptr)
+    if (G.eo != nullptr) {
       load_rows<2>(reinterpret_cast<const T*>(G.eo), GN_FEAT, rb.row_ld, h, in);
-    else
+    } else if (Tb.g[gi].lines) {
+      gather_rows_lines<T>(G, blk, rows, lane, &part[wave][0][0]);
+      __builtin_amdgcn_wave_barrier();
+      read_rows_lines(&part[wave][0][0], lane, in);
+    } else {
       gather_rows<T>(G, rb.row_ld, h, in);
+    }
     Parts<P> xi[2][2];
     make_parts_tiles<P, 2>(in, xi);
     GN_STAMP(unit, 1);
@@ -896,10 +901,16 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
   } else if (any_rows && sub < K) {
     // ---- two-layer form, wpr > 1: types dealt over the waves of a row block, private register rings ------------------
     f32x16 in[2];
-    if (G.eo != nullptr)
+    if (G.eo != nullptr) {
       load_rows<2>(reinterpret_cast<const T*>(G.eo), GN_FEAT, rb.row_ld, h, in);
-    else
+    } else if (Tb.g[gi].lines) {
+      // (every wave of the row block forms the rows itself, in its own scratch; the partial sums reuse it at the end)
+      gather_rows_lines<T>(G, blk, rows, lane, &part[wave][0][0]);
+      __builtin_amdgcn_wave_barrier();
+      read_rows_lines(&part[wave][0][0], lane, in);
+    } else {
       gather_rows<T>(G, rb.row_ld, h, in);
+    }
     Parts<P> xi[2][2];
     make_parts_tiles<P, 2>(in, xi);
     GN_STAMP(unit, 1);

@@ -590,7 +590,82 @@ struct AggGroup {
   gn_agg_group_t a;
   int wpr;
   int stage;   // pair form, wpr == 1: the workgroup stages the per-node pre-activations of its scenes in LDS
+  int lines;   // fused hyper gather accumulated in line layout (agg_x_kernel; needs the launch's `part` LDS)
 };
+
+// eo = H ori of one 32-row block in LINE layout (see scatter_tile_lines in gn_mlp_bf16.hpp for why): lane L = (sub = L / 8,
+// piece = L % 8) accumulates the 16-byte piece `piece` of both 128-byte tiles of the edge rows rg * 8 + sub (rg = 0..3),
+// so one load instruction covers 8 rows' whole lines — and the rows of one scene read the SAME node row, so an
+// instruction touches 2-4 lines instead of 32.  Nodes in ascending order, zero incidences contribute nothing (a select,
+// not a multiply by zero): bit-identical to weighted_rows.  scratch: 32 rows x 72 floats, private to the wave.
+constexpr int kLineRow = 72, kLineTile = 36;
+template <typename T>
+__device__ __forceinline__ void gather_rows_lines(const gn_agg_group_t& G, int blk, int rows, int lane,
+                                                  float* __restrict__ scratch) {
+  const int E = G.E, N = G.N;
+  const int sub = lane >> 3, piece = lane & 7;
+  unsigned oo[4], ho[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const int r = min(blk * 32 + rg * 8 + sub, rows - 1);
+    const int b = r / E;
+    oo[rg] = (unsigned)b * N * GN_FEAT + 4 * piece;
+    ho[rg] = (unsigned)r * N;
+  }
+  const T* ori = reinterpret_cast<const T*>(G.ori);
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[rg][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NB = 3;                          // nodes per batch (their rows are requested together)
+  for (int n0 = 0; n0 < N; n0 += NB) {
+    f32x4 v[NB][4][2];
+    float w[NB][4];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int n = min(n0 + u, N - 1);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        w[u][rg] = G.H[ho[rg] + n];
+        v[u][rg][0] = ld4(ori + oo[rg] + (size_t)n * GN_FEAT);
+        v[u][rg][1] = ld4(ori + oo[rg] + (size_t)n * GN_FEAT + 32);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+      if (n0 + u < N) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const float wv = w[u][rg];
+          const bool on = wv != 0.f;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[rg][t][c] = on ? fmaf(wv, v[u][rg][t][c], acc[rg][t][c]) : acc[rg][t][c];
+        }
+      }
+  }
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      *reinterpret_cast<f32x4*>(scratch + (rg * 8 + sub) * kLineRow + t * kLineTile + 4 * piece) = acc[rg][t];
+}
+// ... and in the MFMA layout (same wave: LDS operations of a wave complete in order)
+__device__ __forceinline__ void read_rows_lines(const float* __restrict__ scratch, int lane, f32x16 (&in)[2]) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + j * kLineRow + t * kLineTile + 8 * q + 4 * h);
+      in[t][4 * q + 0] = v[0];
+      in[t][4 * q + 1] = v[1];
+      in[t][4 * q + 2] = v[2];
+      in[t][4 * q + 3] = v[3];
+    }
+}
 constexpr int kStagePitch = 128 + 4;                 // floats per staged node row (one type)
 constexpr int kStageFloats = 4 * 32 * 64;            // the LDS agg_mlp_kernel owns (shared with the wpr > 1 partial sums)
 constexpr int kStageMaxNodes = kStageFloats / kStagePitch;

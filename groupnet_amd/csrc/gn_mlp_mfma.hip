@@ -1084,8 +1084,14 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
       return gn_check_launch();
     }
   }
-  bool need_part = false;       // LDS for partial sums (wpr > 1) or the staged node rows
-  for (int g = 0; g < n_groups; ++g) need_part = need_part || T.g[g].wpr > 1 || T.g[g].stage != 0;
+  // fused hyper gather in line layout (bf16-core kernels; GN_AGG_LINES = 0 keeps the per-lane gather): needs the LDS too
+  static const bool no_lines = getenv("GN_AGG_LINES") != nullptr && atoi(getenv("GN_AGG_LINES")) == 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_agg_group_t& a = T.g[g].a;
+    T.g[g].lines = (xm && !no_lines && a.A == nullptr && a.eo == nullptr && a.H != nullptr && a.N <= 64) ? 1 : 0;
+  }
+  bool need_part = false;       // LDS for partial sums (wpr > 1), the staged node rows or the line-layout gather
+  for (int g = 0; g < n_groups; ++g) need_part = need_part || T.g[g].wpr > 1 || T.g[g].stage != 0 || T.g[g].lines != 0;
   const size_t part_bytes = need_part ? kAggPartBytes : 0;
   if (twin)
     hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
