@@ -2,7 +2,7 @@
 # CPU side: turn gpurun_out/final (written by tools/final_r02.sh on the GPU box) into the committed profiles/r02_* files.
 set -e
 cd "$(dirname "$0")/.."
-O=gpurun_out/final
+O=gpurun_out/final   # (delete the local copy before a new gpurun: files of earlier runs are merged, not replaced)
 P=profiles
 C="--steps 20 --warmup 5 --no-cpu-baseline --no-train-leg"
 for CFG in c2 c4; do
