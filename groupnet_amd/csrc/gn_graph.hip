@@ -6,6 +6,11 @@
 // wavefront-shuffle reductions, and grids of >> 256 workgroups.
 #include "gn_mlp_common.hpp"
 
+// hyperedges per wave and band whose H rows the node->edge kernel holds in registers (band = 4 waves x this many)
+#ifndef GN_N2E_U
+#define GN_N2E_U 4
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -262,7 +267,7 @@ __device__ __forceinline__ void node2edge_hyper_body(const WaveTable<gn_n2e_grou
   const int total = sg * E;
   // H rows ride one band ahead in registers (N <= 64: one value per lane and edge, up to U edges per wave and band):
   // a wave that loaded each row when it needed it paid one memory latency per hyperedge.
-  constexpr int U = 4;
+  constexpr int U = GN_N2E_U;
   const bool pre = N <= 64 && EB <= U * (kBlock / 64);
   float hn[U];
   auto fetch = [&](int e0n) {
@@ -1030,9 +1035,9 @@ static int node2edge_launch(const gn_n2e_group_t* groups, int n_groups, int B, i
     // most edges any group's workgroup walks
     int maxE = 1;
     for (int g = 0; g < T.n; ++g) maxE = maxE > T.g[g].E ? maxE : T.g[g].E;
-    EBh = (int)(12288 / ((size_t)12 * N + 144));
+    EBh = (int)((size_t)3072 * GN_N2E_U / ((size_t)12 * N + 144));
     EBh = EBh < 4 ? 4 : EBh;
-    if (N <= 64 && EBh > 16) EBh = 16;        // (the band whose H rows a workgroup can hold in registers, see the kernel)
+    if (N <= 64 && EBh > 4 * GN_N2E_U) EBh = 4 * GN_N2E_U;        // (the band whose H rows a workgroup can hold in registers, see the kernel)
     EBh = EBh > SGh * maxE ? SGh * maxE : EBh;
     const size_t scratch = n2e_hyper_scratch_floats(EBh, N) * sizeof(float);
     if ((size_t)SGh * per_scene + scratch > 158 * 1024) return GN_ERR_LDS;

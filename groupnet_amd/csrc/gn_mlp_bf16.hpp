@@ -504,9 +504,10 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
 template <int P, typename T>
 __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void edge_x_kernel(GroupTable<gn_edge_group_t> Tb, float tau,
                                                         unsigned long long seed,
-                                                        const unsigned long long* __restrict__ offset_dev) {
+                                                        const unsigned long long* __restrict__ offset_dev, int pool_bytes) {
   using WS = WStream<P>;
   __shared__ f32x4 wring[WS::kRingF4];
+  extern __shared__ __align__(16) unsigned char pool_dyn[];      // staged x' / pq rows of the pairwise pooling
   const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
   if (lwg < 0) return;
   const int gi = find_group(Tb, lwg);
@@ -519,10 +520,22 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void edge_x_kernel(Gro
   GN_STAMP(unit, 0);
   GN_STAMP(unit, 8);
   f32x16 in[2], z[2], lg;
-  if (G.edges != nullptr)
+  if (G.edges != nullptr) {
     load_rows<2>(reinterpret_cast<const T*>(G.edges), GN_FEAT, rb.row_ld, h, in);
-  else
-    pooled_rows<T>(G, rb.row_ld, h, in);       // fused node -> edge pooling
+  } else {
+    // fused node -> edge pooling; unordered pairs: from the scenes' node rows staged in LDS when they fit
+    const int nodes_max = G.pool_H == nullptr && G.sym_N > 0 ? pool_stage_nodes(128, gn_pair_count(G.pool_N), G.pool_N) : 0;
+    if (nodes_max > 0 && PoolStage<T>::bytes(nodes_max) <= (size_t)pool_bytes) {       // (block-uniform)
+      T* s_xp = reinterpret_cast<T*>(pool_dyn);
+      T* s_pq = s_xp + (size_t)nodes_max * PoolStage<T>::kPitch;
+      const int r0 = (lwg - Tb.first_wg[gi]) * 128;
+      const int node0 = pool_stage_fill<T>(G, r0, min(rows - 1, r0 + 127), s_xp, s_pq);
+      __syncthreads();
+      pooled_rows_staged<T>(G, rb.row_ld, h, s_xp, s_pq, node0, in);
+    } else {
+      pooled_rows<T>(G, rb.row_ld, h, in);
+    }
+  }
   // ordered edge rows whose uniforms this row consumes: itself, or — symmetric pairwise form — the two ordered
   // edges (i,j) and (j,i) of its unordered pair
   long long o1 = rb.row_ld, o2 = rb.row_ld;
@@ -1122,10 +1135,11 @@ __global__ __launch_bounds__(256, 2) void agg_rb2_kernel(GroupTable<AggGroup> Tb
 // two loads of pair A fetch the first two tiles of pair B).
 template <typename T>
 __global__ __launch_bounds__(256, 2) void edge_rb2_kernel(GroupTable<gn_edge_group_t> Tb, float tau, unsigned long long seed,
-                                                          const unsigned long long* __restrict__ offset_dev) {
+                                                          const unsigned long long* __restrict__ offset_dev, int pool_bytes) {
   constexpr int RB = 2;
   using WS = WStream<1, 2>;
   __shared__ f32x4 wring[WS::kRingF4];
+  extern __shared__ __align__(16) unsigned char pool_dyn[];      // staged x' / pq rows of the pairwise pooling
   const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
   if (lwg < 0) return;
   const int gi = find_group(Tb, lwg);
@@ -1143,12 +1157,26 @@ __global__ __launch_bounds__(256, 2) void edge_rb2_kernel(GroupTable<gn_edge_gro
   const float* bd1 = G.bias + 448;
   WS ws;
   ws.begin(G.Wx, wring, lane, wave, 80 / WS::CH);
+  // fused node -> edge pooling of unordered pairs: from the scenes' node rows staged in LDS when they fit
+  const int nodes_max = G.edges == nullptr && G.pool_H == nullptr && G.sym_N > 0
+                            ? pool_stage_nodes(128 * RB, gn_pair_count(G.pool_N), G.pool_N) : 0;
+  const bool staged = nodes_max > 0 && PoolStage<T>::bytes(nodes_max) <= (size_t)pool_bytes;   // (block-uniform)
+  T* s_xp = reinterpret_cast<T*>(pool_dyn);
+  T* s_pq = s_xp + (size_t)nodes_max * PoolStage<T>::kPitch;
+  int node0 = 0;
+  if (staged) {
+    const int r0 = (lwg - Tb.first_wg[gi]) * (128 * RB);
+    node0 = pool_stage_fill<T>(G, r0, min(rows - 1, r0 + 128 * RB - 1), s_xp, s_pq);
+    __syncthreads();
+  }
   Parts<1> xi[RB][2][2];
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
     f32x16 in[2];
     if (G.edges != nullptr)
       load_rows<2>(reinterpret_cast<const T*>(G.edges), GN_FEAT, rb[b].row_ld, h, in);
+    else if (staged)
+      pooled_rows_staged<T>(G, rb[b].row_ld, h, s_xp, s_pq, node0, in);
     else
       pooled_rows<T>(G, rb[b].row_ld, h, in);  // fused node -> edge pooling
     make_parts_tiles<1, 2>(in, xi[b]);

@@ -400,6 +400,96 @@ __device__ __forceinline__ void pooled_rows(const gn_edge_group_t& G, int row, i
     if (hv[n] != 0.f) axpy_row(xp + ((size_t)b * N + n) * GN_FEAT, v[n] / sum * hv[n], h, in, false);
 }
 
+// ---- the pairwise pooling from node rows staged in LDS -----------------------------------------------------------
+// The pair rows of a workgroup belong to a short run of consecutive scenes.  Read per lane from L2 the pooling costs 32
+// load instructions per row block, each touching 32-64 different 128-byte lines (the L1 handles one line per clock):
+// 1-2 k cycles of look-ups per row block — as long as the block's whole matrix work on bf16 storage.  Here the
+// workgroup copies the x' and pq rows of its scenes into LDS once, coalesced (storage type, 16-byte row padding: the
+// 16 lanes of a b128 access phase hit different banks), and the pooling reads them from there; same arithmetic, same
+// order: results identical to pooled_rows.
+template <typename T>
+struct PoolStage {
+  static constexpr int kPiece = 16 / (int)sizeof(T);        // elements per 16-byte piece
+  static constexpr int kPitch = GN_FEAT + kPiece;           // elements per staged row
+  static constexpr int kRowPieces = GN_FEAT / kPiece;
+  __host__ __device__ static constexpr size_t bytes(int nodes) { return (size_t)2 * nodes * kPitch * sizeof(T); }
+};
+// scenes a workgroup of `wg_rows` consecutive pair rows can touch, times N
+__host__ __device__ inline int pool_stage_nodes(int wg_rows, int Pn, int N) { return ((wg_rows - 1) / Pn + 2) * N; }
+// copies the rows of the scenes of pair rows [r0, r1] (all threads of the workgroup; the caller barriers); returns the
+// first staged node
+template <typename T>
+__device__ __forceinline__ int pool_stage_fill(const gn_edge_group_t& G, int r0, int r1, T* __restrict__ s_xp,
+                                               T* __restrict__ s_pq) {
+  using PS = PoolStage<T>;
+  const int N = G.pool_N, Pn = gn_pair_count(N);
+  const int b0 = r0 / Pn, b1 = r1 / Pn;
+  const int node0 = b0 * N, nodes = (b1 - b0 + 1) * N;
+  const T* xp = reinterpret_cast<const T*>(G.xp) + (size_t)node0 * GN_FEAT;
+  const T* pq = reinterpret_cast<const T*>(G.pq) + (size_t)node0 * GN_FEAT;
+  for (int idx = threadIdx.x; idx < nodes * PS::kRowPieces; idx += blockDim.x) {
+    const int r = idx / PS::kRowPieces, c = idx - r * PS::kRowPieces;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xp + (size_t)idx * PS::kPiece);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(pq + (size_t)idx * PS::kPiece);
+    *reinterpret_cast<f32x4*>(s_xp + r * PS::kPitch + c * PS::kPiece) = a;
+    *reinterpret_cast<f32x4*>(s_pq + r * PS::kPitch + c * PS::kPiece) = b;
+  }
+  return node0;
+}
+// pooled_rows, pairwise graph in unordered-pair form, from the staged rows
+template <typename T>
+__device__ __forceinline__ void pooled_rows_staged(const gn_edge_group_t& G, int row, int h, const T* __restrict__ s_xp,
+                                                   const T* __restrict__ s_pq, int node0, f32x16 (&in)[2]) {
+  using PS = PoolStage<T>;
+  const int N = G.pool_N, Pn = gn_pair_count(N);
+  float w2[16];
+  load16(G.w2 + 16 * h, w2);
+  const float b2v = *G.b2;
+  const int b = row / Pn;
+  int i, j;
+  gn_pair_decode(row - b * Pn, N, i, j);
+  const int ri = (b * N + i - node0) * PS::kPitch, rj = (b * N + j - node0) * PS::kPitch;
+  const T* pi = s_pq + ri + 16 * h;
+  const T* pj = s_pq + rj + 16 * h;
+  float Pi[16], Qi[16], Pj[16], Qj[16];
+  load16(pi, Pi);
+  load16(pi + 32, Qi);
+  load16(pj, Pj);
+  load16(pj + 32, Qj);
+  float ai = 0.f, aj = 0.f;
+  float wi, wj;
+  if (i == j) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) ai = fmaf(w2[c], fmaxf(Pi[c] + 2.f * Qi[c], 0.f), ai);
+    ai += __shfl_xor(ai, 32, GN_WAVE);
+    ai += b2v;
+    const float v = 2.f * ai;
+    const float mx = N > 1 ? fmaxf(v, 0.f) : v;
+    const float ev = expf(v - mx);
+    const float sum = ev + gn_nonmember_sum(N - 1, mx);
+    wi = ev / sum * 2.f;
+    wj = 0.f;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float q = Qi[c] + Qj[c];
+      ai = fmaf(w2[c], fmaxf(Pi[c] + q, 0.f), ai);
+      aj = fmaf(w2[c], fmaxf(Pj[c] + q, 0.f), aj);
+    }
+    ai += __shfl_xor(ai, 32, GN_WAVE);
+    aj += __shfl_xor(aj, 32, GN_WAVE);
+    ai += b2v;
+    aj += b2v;
+    const float mx = N > 2 ? fmaxf(fmaxf(ai, aj), 0.f) : fmaxf(ai, aj);
+    const float ei = expf(ai - mx), ej = expf(aj - mx);
+    const float sum = (ei + ej) + gn_nonmember_sum(N - 2, mx);
+    wi = ei / sum;
+    wj = ej / sum;
+  }
+  axpy_row(s_xp + ri, wi, h, in, true);
+  axpy_row(s_xp + rj, wj, h, in, false);
+}
+
 // The 16 pre-activation values lane (j,h) needs of hidden tile t of type k for ONE node: A row + offset.
 struct PreTile {
   f32x4 v[4];

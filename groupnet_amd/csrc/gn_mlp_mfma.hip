@@ -966,6 +966,20 @@ static int edge_launch(const gn_edge_group_t* groups, int n_groups, float tau, u
     wg += row_grid(G.rows);
   }
   T.first_wg[n_groups] = wg;
+  // LDS for the staged node rows of the fused pairwise pooling (the largest any group wants, at most 48 KiB; a group
+  // that would need more pools straight from L2).  GN_POOL_STAGE = 0 switches the stage off.
+  static const bool no_pool_stage = getenv("GN_POOL_STAGE") != nullptr && atoi(getenv("GN_POOL_STAGE")) == 0;
+  auto pool_bytes_for = [&](int wg_rows) {
+    size_t need = 0;
+    for (int g = 0; g < n_groups && !no_pool_stage; ++g) {
+      const gn_edge_group_t& G = groups[g];
+      if (G.edges != nullptr || G.pool_H != nullptr || G.sym_N <= 0) continue;
+      const int nodes = pool_stage_nodes(wg_rows, gn_pair_count(G.pool_N), G.pool_N);
+      const size_t b = twin ? PoolStage<__bf16>::bytes(nodes) : PoolStage<float>::bytes(nodes);
+      if (b <= 48 * 1024 && b > need) need = b;
+    }
+    return need;
+  };
   if (twin) {
     // a large launch: two row blocks per wave (edge_rb2_kernel); GN_EDGE_RB2 = 0 / 1 forces the choice (parity tests)
     long long pairs = 0;
@@ -979,13 +993,20 @@ static int edge_launch(const gn_edge_group_t* groups, int n_groups, float tau, u
         wg += ((groups[g].rows + 31) / 32 + 7) / 8;
       }
       T.first_wg[n_groups] = wg;
-      hipLaunchKernelGGL((edge_rb2_kernel<__bf16>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T, tau, seed, offset_dev);
+      const size_t pb = pool_bytes_for(256);
+      hipLaunchKernelGGL((edge_rb2_kernel<__bf16>), dim3(table_xcd_grid(T)), dim3(256), pb, stream, T, tau, seed, offset_dev,
+                         (int)pb);
       return gn_check_launch();
     }
-    hipLaunchKernelGGL((edge_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T, tau, seed, offset_dev);
+    const size_t pb = pool_bytes_for(128);
+    hipLaunchKernelGGL((edge_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), pb, stream, T, tau, seed, offset_dev,
+                       (int)pb);
   }
-  else if (xm)
-    hipLaunchKernelGGL((edge_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T, tau, seed, offset_dev);
+  else if (xm) {
+    const size_t pb = pool_bytes_for(128);
+    hipLaunchKernelGGL((edge_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), pb, stream, T, tau, seed, offset_dev,
+                       (int)pb);
+  }
   else
     hipLaunchKernelGGL(edge_mlp_gumbel_kernel, dim3(wg), dim3(256), 0, stream, T, tau, seed, offset_dev);
   return gn_check_launch();

@@ -1066,3 +1066,28 @@ def test_mlp2_xs_kernel_equals_the_one_wave_per_block_kernel(B, N, scales, nmp, 
     assert torch.equal(outs["0"][1], outs["1"][1])
     assert torch.isfinite(b).all()
     assert err <= (2e-6 if dtype == torch.float32 else 1.6e-2)
+
+
+@pytest.mark.parametrize("dtype,B,N,scales", [(torch.float32, 7, 11, [2, 5, 11]), (torch.float32, 3, 5, [2]),
+                                               (torch.bfloat16, 3, 50, [4, 16]), (torch.float32, 2, 70, [8])])
+def test_staged_pairwise_pooling_is_bit_identical(dtype, B, N, scales, monkeypatch):
+    """The fused node->edge pooling of the pairwise graph reads the scenes' x' / pq rows from an LDS stage (the workgroup
+    copies them once, coalesced) or, GN_POOL_STAGE=0 / rows that do not fit, per lane from L2: same arithmetic in the
+    same order, so every output is identical bit for bit (N=50 bf16: the two-row-blocks-per-wave kernel and a workgroup
+    spanning two scenes; N=70: 2485 pairs per scene)."""
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    torch.manual_seed(9)
+    blk = MultiScaleHGNN(scales).to(dev()).eval()
+    f = torch.randn(B, N, 64, device=dev()).to(dtype)
+    U = [[torch.rand(s, device=dev())] for s in blk.noise_shapes(B, N)]
+    outs = {}
+    with torch.no_grad():
+        for st in ("0", "1"):
+            monkeypatch.setenv("GN_POOL_STAGE", st)
+            if dtype == torch.bfloat16:
+                monkeypatch.setenv("GN_EDGE_RB2", "1")
+            outs[st] = blk(f, noise_u=U)
+            _, fac = blk.interaction(f, noise_u=U[0])
+            outs[st] = (*outs[st], fac)
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
