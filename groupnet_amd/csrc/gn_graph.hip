@@ -57,9 +57,39 @@ __device__ __forceinline__ void emit_incidence(const float* row, int N, int b, i
   }
 }
 
+// Ranking key of affinity v in column j of its row: key_j > key_c  <=>  beats(v_j, j, v_c, c).  High word: the float's
+// bits mapped to an order-preserving unsigned (-0 folded into +0: the two compare equal; every NaN -> the largest key:
+// NaN ranks first), low word: ~j (the lower index wins a tie).  One 64-bit compare per (j, c) instead of the
+// NaN / greater / equal / index cascade — the ranking was the larger half of this kernel at N = 50.
+__device__ __forceinline__ unsigned long long rank_key(float v, int j) {
+  const float z = v + 0.f;                                   // -0 -> +0
+  const uint32_t b = __float_as_uint(z);
+  uint32_t s = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  s = (z != z) ? 0xFFFFFFFFu : s;
+  return ((unsigned long long)s << 32) | (uint32_t)(~(uint32_t)j);
+}
+// the writes of every scale for column c of row i, given its rank
+template <typename T>
+__device__ __forceinline__ void emit_ranked(int rank, int N, int b, int i, int c, const ScaleList& sl) {
+  T* H_cat = reinterpret_cast<T*>(sl.H_cat);   // the concatenation is what the caller returns: storage type T
+  for (int s = 0; s < sl.n; ++s) {
+    if (sl.k[s] == N) {
+      if (i == 0) {
+        sl.H[s][(size_t)b * N + c] = 1.f;
+        if (H_cat) st1(H_cat + ((size_t)b * sl.cat_rows + sl.cat_off[s]) * N + c, 1.f);
+      }
+    } else {
+      const float v = rank < sl.k[s] ? 1.f : 0.f;
+      sl.H[s][((size_t)b * N + i) * N + c] = v;
+      if (H_cat) st1(H_cat + ((size_t)b * sl.cat_rows + sl.cat_off[s] + i) * N + c, v);
+    }
+  }
+}
+
 // One workgroup per scene.  f rows are normalised into LDS (stride D+4 floats keeps the
-// 16-byte row reads of different rows on different banks), corr is formed in LDS, optionally
-// written out, and ranked in place.  Needs N*(D+4 + N)*4 bytes of LDS.
+// 16-byte row reads of different rows on different banks); corr is formed once per UNORDERED pair (the dot product
+// is symmetric term by term, so corr[j][i] is the same bits), optionally written out, and kept in LDS as ranking keys,
+// which are then ranked in place.  Needs N*(D+4)*4 + N*N*8 bytes of LDS.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void affinity_topk_kernel(const T* __restrict__ f, float* __restrict__ corr,
                                                                ScaleList sl, int N, int D, gn_block_extras_t ex) {
@@ -67,11 +97,11 @@ __global__ __launch_bounds__(kBlock) void affinity_topk_kernel(const T* __restri
   const int b = blockIdx.x;
   const int ldq = D + 4;
   float* q = lds;             // N x ldq
-  float* cr = lds + N * ldq;  // N x N
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds + N * ldq + ((N * ldq) & 1));  // N x N, 8-byte aligned
   const T* fb = f + (size_t)b * N * D;
   const int d4 = D >> 2;
   if (ex.counter != nullptr && b == 0 && threadIdx.x == 0) *ex.counter += ex.counter_add;
-  float* xs = cr + N * N;  // N x x_dim raw inputs (embedding form only)
+  float* xs = reinterpret_cast<float*>(keys + N * N);  // N x x_dim raw inputs (embedding form only)
   if (ex.x_raw != nullptr) {
     const float* xb = ex.x_raw + (size_t)b * N * ex.x_dim;
     for (int idx = threadIdx.x; idx < N * ex.x_dim; idx += kBlock) xs[idx] = xb[idx];
@@ -109,8 +139,10 @@ __global__ __launch_bounds__(kBlock) void affinity_topk_kernel(const T* __restri
     for (int d = lane; d < D; d += 64) q[r * ldq + d] = q[r * ldq + d] / denom;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < N * N; idx += kBlock) {
-    const int i = idx / N, j = idx - i * N;
+  const int Pn = gn_pair_count(N);
+  for (int p = threadIdx.x; p < Pn; p += kBlock) {
+    int i, j;
+    gn_pair_decode(p, N, i, j);
     const f32x4* a = reinterpret_cast<const f32x4*>(q + i * ldq);
     const f32x4* c = reinterpret_cast<const f32x4*>(q + j * ldq);
     float acc = 0.f;
@@ -121,14 +153,22 @@ __global__ __launch_bounds__(kBlock) void affinity_topk_kernel(const T* __restri
       acc = fmaf(x[2], y[2], acc);
       acc = fmaf(x[3], y[3], acc);
     }
-    cr[idx] = acc;
-    if (corr) corr[(size_t)b * N * N + idx] = acc;
+    keys[i * N + j] = rank_key(acc, j);
+    keys[j * N + i] = rank_key(acc, i);
+    if (corr) {
+      corr[(size_t)b * N * N + i * N + j] = acc;
+      corr[(size_t)b * N * N + j * N + i] = acc;
+    }
   }
   if (sl.n == 0) return;
   __syncthreads();
   for (int idx = threadIdx.x; idx < N * N; idx += kBlock) {
     const int i = idx / N, c = idx - i * N;
-    emit_incidence<T>(cr + i * N, N, b, i, c, sl);
+    const unsigned long long* row = keys + i * N;
+    const unsigned long long kc = row[c];
+    int rank = 0;
+    for (int j = 0; j < N; ++j) rank += row[j] > kc ? 1 : 0;
+    emit_ranked<T>(rank, N, b, i, c, sl);
   }
 }
 
@@ -883,7 +923,7 @@ extern "C" int gn_affinity_f32(const float* f, float* corr, int B, int N, int D,
   GN_REQUIRE_PTR(corr);
   GN_REQUIRE_ALIGNED(f);
   if (B <= 0 || N <= 0 || D <= 0 || (D & 3) || D > 1024) return GN_ERR_SHAPE;
-  const size_t fused = (size_t)N * (D + 4 + N) * sizeof(float);
+  const size_t fused = (size_t)N * (D + 4) * sizeof(float) + 8 + (size_t)N * N * 8;
   if (fused <= kLdsBudget) {
     ScaleList sl{};
     sl.n = 0;
@@ -956,7 +996,7 @@ static int affinity_topk_launch(const TS* f, float* corr, float* const* H_list, 
   ScaleList sl;
   const int rc = fill_scales(sl, H_list, k_list, n_scales, N);
   if (rc != GN_OK) return rc;
-  size_t fused = (size_t)N * (D + 4 + N) * sizeof(float);
+  size_t fused = (size_t)N * (D + 4) * sizeof(float) + 8 + (size_t)N * N * 8;
   if (embed) {
     if (extras->x_dim <= 0 || !extras->M || !extras->c || !extras->f_contig) return GN_ERR_NULL;
     if (!gn_aligned16(extras->c) || !gn_aligned16(extras->f_contig)) return GN_ERR_ALIGN;

@@ -193,7 +193,7 @@ def listall_incidence(corr: Tensor, scale: int) -> Tensor:
 
 def fused_affinity_fits(N: int, D: int, x_dim: int = 0) -> bool:
     """Whether one scene's tile of the fused affinity+top-k launch fits its 128 KiB LDS budget."""
-    return N * (D + 4 + N + x_dim) * 4 <= 128 * 1024
+    return N * (D + 4 + x_dim) * 4 + 8 + N * N * 8 <= 128 * 1024      # rows + 64-bit ranking keys (+ raw inputs)
 
 
 def affinity_topk(f: Optional[Tensor], scales: Sequence[int], want_corr: bool = True, f_out: Optional[Tensor] = None,
