@@ -1107,6 +1107,14 @@ extern "C" int gn_node2edge_bf16(const gn_n2e_group_t* groups, int n_groups, int
   return node2edge_launch<__bf16>(groups, n_groups, B, N, (hipStream_t)stream);
 }
 
+// workgroups a gather / scatter launch keeps at least when it packs several scenes into one (GN_GS_MIN_WGS).  2048 = two
+// rounds of the chip at B = 4096, N = 11: the second round's loads overlap the first one's stores (3.90 -> 4.12 TB/s for
+// the pair; 4096 and 8192 measured the same as 2048)
+static int gs_min_wgs() {
+  static const int v = getenv("GN_GS_MIN_WGS") != nullptr ? atoi(getenv("GN_GS_MIN_WGS")) : 2048;
+  return v;
+}
+
 template <typename TS>
 static int gather_launch(const gn_gather_group_t* groups, int n_groups, int B, int N, hipStream_t s) {
   int rc = check_groups(groups, n_groups);
@@ -1146,7 +1154,7 @@ static int gather_launch(const gn_gather_group_t* groups, int n_groups, int B, i
     const size_t per_scene = ori_b + (size_t)Emax * N * sizeof(float);
     if (per_scene <= kLdsBudget) {
       // several scenes per workgroup while the tile stays <= 24 KiB and the grid stays >= 1024
-      while (G < 16 && (size_t)(2 * G) * per_scene <= 24 * 1024 && (long long)((B + 2 * G - 1) / (2 * G)) * nh >= 1024)
+      while (G < 16 && (size_t)(2 * G) * per_scene <= 24 * 1024 && (long long)((B + 2 * G - 1) / (2 * G)) * nh >= gs_min_wgs())
         G *= 2;
     } else {
       TE = (int)((kLdsBudget - ori_b) / ((size_t)N * sizeof(float)));
@@ -1205,7 +1213,7 @@ static int scatter_launch(const gn_scatter_group_t* groups, int n_groups, int B,
   if (nh > 0) {
     const size_t per_scene = (size_t)Emax * (GN_FEAT + N) * sizeof(float);
     int G = 1;
-    while (G < 16 && (size_t)(2 * G) * per_scene <= 24 * 1024 && (long long)((B + 2 * G - 1) / (2 * G)) * nh >= 1024)
+    while (G < 16 && (size_t)(2 * G) * per_scene <= 24 * 1024 && (long long)((B + 2 * G - 1) / (2 * G)) * nh >= gs_min_wgs())
       G *= 2;
     gn_allow_big_lds(agg_scatter_kernel<TS>);
     hipLaunchKernelGGL(agg_scatter_kernel<TS>, dim3((B + G - 1) / G, nh), dim3(kBlock), (size_t)G * per_scene, s, T, B,
