@@ -136,6 +136,10 @@ __device__ __forceinline__ int find_group(const GroupTable<G>& t, int wg) {
 template <bool FAST = false>
 __device__ __forceinline__ void gumbel_softmax_row(const f32x16& lg, const float (&u)[8], int K, float tau, int h,
                                                    float (&d)[8]) {
+#ifdef GN_DIAG_NO_GUMBEL     // diagnostic builds only (results are wrong)
+  for (int r = 0; r < 8; ++r) d[r] = lg[r] * u[r];
+  return;
+#endif
   const float eps = 1e-10f;  // MS_HGNN_batch.py:446
   float y[8];
   float m = -INFINITY;
@@ -187,6 +191,10 @@ __device__ __forceinline__ void gumbel_softmax_row(const f32x16& lg, const float
 // blocks, which are evaluated once and shared by the run's elements (one block per ELEMENT was 4 evaluations per run).
 __device__ __forceinline__ void fetch_uniforms(const float* __restrict__ U, unsigned long long base,
                                                unsigned long long seed, long long orow, int K, int h, float (&u)[8]) {
+#ifdef GN_DIAG_NO_PHILOX     // diagnostic builds only (results are wrong): what the edge kernels take without the generator
+  for (int r = 0; r < 8; ++r) u[r] = 0.5f;
+  return;
+#endif
   if (U != nullptr) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -441,6 +449,11 @@ template <typename T>
 __device__ __forceinline__ void pooled_rows_staged(const gn_edge_group_t& G, int row, int h, const T* __restrict__ s_xp,
                                                    const T* __restrict__ s_pq, int node0, f32x16 (&in)[2]) {
   using PS = PoolStage<T>;
+#ifdef GN_DIAG_NO_POOL       // diagnostic builds only (results are wrong)
+  for (int t = 0; t < 2; ++t)
+    for (int r = 0; r < 16; ++r) in[t][r] = s_xp[(row & 15) * PS::kPitch + r];
+  return;
+#endif
   const int N = G.pool_N, Pn = gn_pair_count(N);
   float w2[16];
   load16(G.w2 + 16 * h, w2);
