@@ -438,6 +438,186 @@ __device__ __forceinline__ void node2edge_hyper_body(const WaveTable<gn_n2e_grou
   }
 }
 
+// Hyper modules, one LANE PAIR per hyperedge (N <= 64).  The banded form above walks each band of hyperedges through five
+// barrier-separated phases (member lists, Q, logits, softmax, pooling) that hand everything over through LDS scratch:
+// at N = 50, B = 1024 a workgroup lived ~25 us for a few microseconds of arithmetic (20 barriers, 4 workgroups per
+// CU).  Here the scenes' x' / pq rows are staged once (row pitch 68 floats: lanes that read different rows at the same
+// offset hit different banks) and lane (r, h) of a row's pair then does the whole row on its own 16 of the 32 attention
+// channels / 32 of the 64 features: members from a 64-bit mask of its incidence row, Q = sum H Qn, the logits twice
+// (first pass: running max and sum of the softmax over ALL N nodes; second pass: the weights), the pooled features —
+// no scratch, no barrier after the stage.  Same formulas as the banded form (softmax(att*H)*H incl. the non-members'
+// exp(0 - max)); the running max/sum rounds differently in the last bits.
+constexpr int kRowPitch = GN_FEAT + 4;
+template <typename TS>
+__device__ __forceinline__ void node2edge_hyper_rows_body(const WaveTable<gn_n2e_group_t>& T, int B, int N, int SG, int wg) {
+  extern __shared__ __align__(16) float lds[];
+  const int gi = gn_uniform(find_wave_group(T, wg));
+  const gn_n2e_group_t G = T.g[gi];
+  const int E = G.E;
+  const int b0 = (int)(wg - T.first[gi]) * SG;
+  const int sg = min(SG, B - b0);
+  float* s_xp = lds;                                      // sg x N x 68
+  float* s_pq = s_xp + (size_t)SG * N * kRowPitch;        // sg x N x 68
+  {
+    const TS* xs = reinterpret_cast<const TS*>(G.xp) + (size_t)b0 * N * GN_FEAT;
+    const TS* ps = reinterpret_cast<const TS*>(G.pq) + (size_t)b0 * N * GN_FEAT;
+    for (int idx = threadIdx.x; idx < sg * N * 16; idx += kBlock) {
+      const int r = idx >> 4, c = idx & 15;
+      *reinterpret_cast<f32x4*>(s_xp + r * kRowPitch + 4 * c) = ld4(xs + 4 * idx);
+      *reinterpret_cast<f32x4*>(s_pq + r * kRowPitch + 4 * c) = ld4(ps + 4 * idx);
+    }
+  }
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  float w2[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) w2[c] = G.w2[16 * h + c];
+  const float b2v = *G.b2;
+  __syncthreads();
+  const int total = sg * E;
+  for (int r0 = 0; r0 < total; r0 += kBlock / 2) {
+    const int r = r0 + (threadIdx.x >> 6) * 32 + (lane & 31);       // this lane pair's hyperedge (wave w: rows 32w ..)
+    const bool live = r < total;
+    const int rr = live ? r : total - 1;
+    const int s = rr / E;
+    const float* Hrow = G.H + ((size_t)b0 * E + rr) * N;
+    const float* pqb = s_pq + (size_t)s * N * kRowPitch;
+    const float* xpb = s_xp + (size_t)s * N * kRowPitch;
+    // members: lane h scans the nodes n = h, h+2, ...; the pair ORs its halves
+    unsigned long long mask = 0ull;
+    for (int n = h; n < N; n += 2) mask |= (unsigned long long)(Hrow[n] != 0.f) << n;
+    {
+      const unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);
+      const unsigned olo = (unsigned)__shfl_xor((int)lo, 32, GN_WAVE), ohi = (unsigned)__shfl_xor((int)hi, 32, GN_WAVE);
+      mask |= ((unsigned long long)ohi << 32) | olo;
+    }
+    const int cnt = __popcll(mask);
+    float Q[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Q[c] = 0.f;
+    f32x4 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto logit = [&](int n, float hv) {                    // (att[e,n] + b2) * H[e,n]
+      const float* pp = pqb + n * kRowPitch + 16 * h;
+      float t = 0.f;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pp + 4 * c4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t = fmaf(w2[4 * c4 + c], fmaxf(v[c] + Q[4 * c4 + c], 0.f), t);
+      }
+      t += __shfl_xor(t, 32, GN_WAVE);
+      return (t + b2v) * hv;
+    };
+    constexpr int MK = 16;
+    if (__all(cnt <= MK)) {
+      // up to 16 members (every top-k scale of the reference): member list and logits in registers, loops unrolled so
+      // that the LDS reads of several members are in flight together; max first, then the sum, as the banded form
+      int mem[MK];
+      float hvv[MK], vv[MK];
+      {
+        unsigned long long m = mask;
+#pragma unroll
+        for (int k = 0; k < MK; ++k) {
+          mem[k] = m != 0ull ? __builtin_ctzll(m) : 0;
+          hvv[k] = k < cnt ? Hrow[mem[k]] : 0.f;
+          m &= m - 1ull;                                   // (0 stays 0)
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < MK; ++k)
+        if (k < cnt) {
+          const float* q = pqb + mem[k] * kRowPitch + 32 + 16 * h;
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(q + 4 * c4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Q[4 * c4 + c] = fmaf(hvv[k], v[c], Q[4 * c4 + c]);
+          }
+        }
+      float mx = cnt < N ? 0.f : -INFINITY;
+#pragma unroll
+      for (int k = 0; k < MK; ++k) {
+        vv[k] = 0.f;
+        if (__any(k < cnt)) {                              // (the shuffle inside needs both lanes of a pair)
+          const float v = logit(mem[k], hvv[k]);
+          if (k < cnt) {
+            vv[k] = v;
+            mx = fmaxf(mx, v);
+          }
+        }
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < MK; ++k)
+        if (k < cnt) {
+          vv[k] = expf(vv[k] - mx);
+          sum += vv[k];
+        }
+      sum += gn_nonmember_sum(N - cnt, mx);
+#pragma unroll
+      for (int k = 0; k < MK; ++k)
+        if (k < cnt) {
+          const float w = vv[k] / sum * hvv[k];
+          const float* x = xpb + mem[k] * kRowPitch + 32 * h;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[q][c] = fmaf(w, v[c], acc[q][c]);
+          }
+        }
+    } else {
+      // any number of members: running max / sum of the softmax, logits evaluated a second time for the weights
+      for (unsigned long long m = mask; m != 0ull; m &= m - 1ull) {
+        const int n = __builtin_ctzll(m);
+        const float hv = Hrow[n];
+        const float* q = pqb + n * kRowPitch + 32 + 16 * h;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(q + 4 * c4);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Q[4 * c4 + c] = fmaf(hv, v[c], Q[4 * c4 + c]);
+        }
+      }
+      // (lanes of rows with fewer members idle through the longer rows' iterations: the shuffle needs the whole pair)
+      float mx = cnt < N ? 0.f : -INFINITY, sum = 0.f;
+      for (unsigned long long m = mask; __any(m != 0ull); m &= m - 1ull) {
+        const bool on = m != 0ull;
+        const int n = on ? __builtin_ctzll(m) : 0;
+        const float v = logit(n, Hrow[n]);
+        if (on) {
+          const float nm = fmaxf(mx, v);
+          sum = sum * expf(mx - nm) + expf(v - nm);
+          mx = nm;
+        }
+      }
+      sum += gn_nonmember_sum(N - cnt, mx);
+      for (unsigned long long m = mask; __any(m != 0ull); m &= m - 1ull) {
+        const bool on = m != 0ull;
+        const int n = on ? __builtin_ctzll(m) : 0;
+        const float hv = Hrow[n];
+        const float lv = logit(n, hv);
+        if (on) {
+          const float w = expf(lv - mx) / sum * hv;
+          const float* x = xpb + n * kRowPitch + 32 * h;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[q][c] = fmaf(w, v[c], acc[q][c]);
+          }
+        }
+      }
+    }
+    if (live) {
+      TS* out = reinterpret_cast<TS*>(G.edges) + ((size_t)b0 * E + r) * GN_FEAT + 32 * h;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) st4(out + 4 * q, acc[q]);
+    }
+  }
+}
+
 // Pairwise module (MS_HGNN_oridinary): edge e = i*N + j touches i and j with weight 1 (2 on the
 // diagonal), so only att[e,i] and att[e,j] matter and Q_e = Qn_i + Qn_j.  A workgroup stages the
 // x' and pq rows of SG scenes in LDS (pq rows padded to 65 floats: lanes read different rows at the
@@ -545,7 +725,9 @@ struct PairTable {
   int SG[GN_MAX_GROUPS], bands[GN_MAX_GROUPS];
   int n;
 };
-template <typename TS>
+// ROWS: the hyper groups in the lane-pair-per-hyperedge form (a kernel of its own: that form keeps member lists and
+// logits in registers, which the banded form's occupancy must not pay for)
+template <typename TS, bool ROWS>
 __global__ __launch_bounds__(kBlock) void node2edge_kernel(WaveTable<gn_n2e_group_t> T, PairTable pair, int B, int N,
                                                            int SGh, int EBh, XcdSections xs) {
   const int wg = gn_uniform(gn_xcd_logical(xs, blockIdx.x));     // sections: the pairwise groups, then the hyper groups
@@ -555,6 +737,8 @@ __global__ __launch_bounds__(kBlock) void node2edge_kernel(WaveTable<gn_n2e_grou
     int g = 0;
     while (g + 1 < pair.n && wg >= pair.first_wg[g + 1]) ++g;
     node2edge_pairwise_body<TS>(pair.g[g], B, N, pair.SG[g], pair.bands[g], wg - pair.first_wg[g]);
+  } else if constexpr (ROWS) {
+    node2edge_hyper_rows_body<TS>(T, B, N, SGh, wg - n_pair_wgs);      // one lane pair per hyperedge (N <= 64)
   } else {
     node2edge_hyper_body<TS>(T, B, N, SGh, EBh, wg - n_pair_wgs);
   }
@@ -1079,9 +1263,32 @@ static int node2edge_launch(const gn_n2e_group_t* groups, int n_groups, int B, i
     EBh = EBh < 4 ? 4 : EBh;
     if (N <= 64 && EBh > 4 * GN_N2E_U) EBh = 4 * GN_N2E_U;        // (the band whose H rows a workgroup can hold in registers, see the kernel)
     EBh = EBh > SGh * maxE ? SGh * maxE : EBh;
-    const size_t scratch = n2e_hyper_scratch_floats(EBh, N) * sizeof(float);
-    if ((size_t)SGh * per_scene + scratch > 158 * 1024) return GN_ERR_LDS;
-    const size_t l = (size_t)SGh * per_scene + scratch;
+    size_t scratch = n2e_hyper_scratch_floats(EBh, N) * sizeof(float);
+    size_t stage = (size_t)SGh * per_scene;
+    // N <= 64: one lane pair per hyperedge (no scratch, no barriers after the stage); scenes per workgroup so that
+    // ~100 of the 128 pairs have a row, the stage stays <= 56 KiB and the grid keeps >= 1024 workgroups.
+    // GN_N2E_ROWS = 0 keeps the banded form, 1 forces this one (parity tests).
+    const char* rows_env = getenv("GN_N2E_ROWS");                 // 0: never, 1: whenever N <= 64, unset: by launch size
+    const bool no_rows = rows_env != nullptr && atoi(rows_env) == 0;
+    const bool force_rows = rows_env != nullptr && atoi(rows_env) != 0;
+    long long hyper_rows = 0;
+    for (int g = 0; g < T.n; ++g) hyper_rows += (long long)B * T.g[g].E;
+    // (few short scenes cannot fill the 128 lane pairs of a workgroup AND the chip.  Measured, banded vs rows, us —
+    // N = 11: B = 512 10.6 / 21.0, 1024 15.3 / 19.1, 2048 25.0 / 24.3, 4096 42.1 / 39.1;
+    // N = 50: B = 32 23.7 / 14.8, 128 25.9 / 18.4, 256 32.1 / 31.9, 1024 104 / 79)
+    if (N <= 64 && !no_rows && (maxE >= 24 || hyper_rows >= 49152 || force_rows)) {
+      const size_t row_scene = (size_t)2 * N * kRowPitch * sizeof(float);
+      SGh = 1;
+      while ((SGh + 1) * maxE <= kBlock / 2 && (size_t)(SGh + 1) * row_scene <= 56 * 1024 &&
+             (long long)((B + SGh) / (SGh + 1)) * T.n >= 1024)
+        ++SGh;
+      if (const char* e = getenv("GN_N2E_ROWS_SG")) SGh = atoi(e) > 0 ? atoi(e) : SGh;     // (tuning)
+      EBh = 0;
+      scratch = 0;
+      stage = (size_t)SGh * row_scene;
+    }
+    if (stage + scratch > 158 * 1024) return GN_ERR_LDS;
+    const size_t l = stage + scratch;
     lds = lds > l ? lds : l;
     for (int g = 0; g < T.n; ++g) {
       T.first[g] = waves;
@@ -1096,8 +1303,15 @@ static int node2edge_launch(const gn_n2e_group_t* groups, int n_groups, int B, i
   for (int g = 0; g < T.n; ++g) xs.first[xs.n++] = pair_wgs + (int)T.first[g];
   xs.first[xs.n] = (int)grid;
   // (pairwise workgroups are (scene chunk, band) with the band fastest: scene order, like every other stage)
-  gn_allow_big_lds(node2edge_kernel<TS>);
-  hipLaunchKernelGGL(node2edge_kernel<TS>, dim3((unsigned)gn_xcd_grid(xs)), dim3(kBlock), lds, s, T, P, B, N, SGh, EBh, xs);
+  if (T.n > 0 && EBh == 0) {
+    gn_allow_big_lds(node2edge_kernel<TS, true>);
+    hipLaunchKernelGGL((node2edge_kernel<TS, true>), dim3((unsigned)gn_xcd_grid(xs)), dim3(kBlock), lds, s, T, P, B, N, SGh,
+                       EBh, xs);
+  } else {
+    gn_allow_big_lds(node2edge_kernel<TS, false>);
+    hipLaunchKernelGGL((node2edge_kernel<TS, false>), dim3((unsigned)gn_xcd_grid(xs)), dim3(kBlock), lds, s, T, P, B, N, SGh,
+                       EBh, xs);
+  }
   return gn_check_launch();
 }
 extern "C" int gn_node2edge_f32(const gn_n2e_group_t* groups, int n_groups, int B, int N, gn_stream_t stream) {

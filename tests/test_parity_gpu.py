@@ -1091,3 +1091,37 @@ def test_staged_pairwise_pooling_is_bit_identical(dtype, B, N, scales, monkeypat
             outs[st] = (*outs[st], fac)
     for a, b in zip(outs["0"], outs["1"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,scales", [(5, 11, [2, 5, 11]), (3, 50, [2, 4, 8, 16]), (4, 30, [20, 30]), (70, 3, [1, 2]),
+                                        (2, 64, [7])])
+def test_node2edge_row_form_equals_the_banded_form(B, N, scales, dtype, monkeypatch):
+    """The hyper modules' node->edge pooling with one lane pair per hyperedge (what large launches run; GN_N2E_ROWS=1
+    forces it) against the banded form on the same x', pq and incidences — incl. rows with more than 16 members (the
+    generic path: running max / sum), scale == N (one full hyperedge), a mix of groups in one launch, ragged last
+    workgroups, and hand-made rows: empty, and weights other than 1.  fp32: 2e-6 of the output scale (different summation
+    order of the softmax); bf16 storage: one rounding of the stored result."""
+    from groupnet_amd import ops
+    torch.manual_seed(17)
+    items = []
+    for s in scales:
+        xp = torch.randn(B, N, 64, device=dev()).to(dtype)
+        pq = torch.randn(B, N, 64, device=dev()).to(dtype)
+        corr = torch.rand(B, N, N, device=dev())
+        H = ops.topk_incidence(corr, [s])[0].clone()
+        if s != N and B > 1:
+            H[0, 0, :] = 0.0                          # an empty hyperedge
+            H[1, min(1, H.shape[1] - 1), :] *= 1.5    # weights other than 0 / 1
+        w2 = torch.randn(32, device=dev())
+        b2 = torch.randn(1, device=dev())
+        items.append((xp, pq, H, w2, b2))
+    outs = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("GN_N2E_ROWS", v)
+        outs[v] = [e.float() for e in ops.node2edge_grouped(items)]
+    for a, b, s in zip(outs["0"], outs["1"], scales):
+        assert a.shape == b.shape and torch.isfinite(b).all()
+        err = float((a - b).abs().max()) / max(1.0, float(a.abs().max()))
+        print(f"\nnode2edge rows vs banded ({dtype}, B={B} N={N} scale={s}): max rel diff {err:.2e}")
+        assert err <= (2e-6 if dtype == torch.float32 else 8e-3)
