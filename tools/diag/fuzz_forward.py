@@ -9,6 +9,8 @@ from oracle import ms_hgnn_oracle as O
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+BF16 = len(sys.argv) > 3 and sys.argv[3] == "bf16"      # the twins: bf16-rounded input, gate 1.5e-2 of scale, H on rows
+GATE, GAP = (1.5e-2, 2e-2) if BF16 else (1e-5, 1e-6)     # whose top-k boundary is wider than GAP
 dev = torch.device("cuda")
 worst = 0.0
 for it in range(cases):
@@ -25,6 +27,8 @@ for it in range(cases):
     shs = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in blk.interaction_hyper]
     blk.to(dev).eval()
     h = torch.randn(B, N, 64)
+    if BF16:
+        h = h.bfloat16().float()
     noise = [[torch.rand(s) for _ in range(nmp)] for s in blk.noise_shapes(B, N)]
     with torch.no_grad():
         # (ms_hgnn_multiscale_forward is the nmp_layers = 1 block: assemble the general case from the module functions)
@@ -36,7 +40,8 @@ for it in range(cases):
             feats.append(nf)
             Hl.append(Hm)
         ref, Href = torch.cat(feats, dim=-1), (torch.cat(Hl, dim=1) if Hl else None)
-        out, H = blk(h.to(dev), noise_u=[[u.to(dev) for u in n] for n in noise])
+        out, H = blk((h.bfloat16() if BF16 else h).to(dev), noise_u=[[u.to(dev) for u in n] for n in noise])
+        out, H = out.float(), (H.float() if H is not None else None)
     err = float((out.cpu() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
     hok = True
     if scales:
@@ -47,12 +52,12 @@ for it in range(cases):
             got, want = H.cpu()[:, row0:row0 + E], Href[:, row0:row0 + E]
             if s != N:
                 v = torch.sort(corr, dim=-1, descending=True).values
-                ok = (v[..., s - 1] - v[..., s]) > 1e-6
+                ok = (v[..., s - 1] - v[..., s]) > GAP
                 hok = hok and torch.equal(got[ok], want[ok])
             else:
                 hok = hok and torch.equal(got, want)
             row0 += E
     worst = max(worst, err)
-    flag = "" if (err <= 1e-5 and hok and torch.isfinite(out).all()) else "   <<<<<< FAIL"
+    flag = "" if (err <= GATE and hok and torch.isfinite(out).all()) else "   <<<<<< FAIL"
     print(f"case {it:3d}: B={B:3d} N={N:3d} scales={scales} nmp={nmp} xs={xs}  rel err {err:.2e}  H {'ok' if hok else 'DIFF'}{flag}")
 print(f"worst relative error {worst:.2e}")
