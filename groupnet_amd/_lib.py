@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -73,6 +73,16 @@ class SplitJob(ctypes.Structure):      # gn_split_job_t
     _fields_ = [("packed", _P), ("out", _P), ("n_tiles", _I), ("reserved", _I)]
 
 
+class GumbelBwdGroup(ctypes.Structure):  # gn_gumbel_bwd_group_t
+    _fields_ = [("dist", _P), ("lgf", _P), ("def_", _P), ("gdist", _P), ("dlgf", _P), ("rows", ctypes.c_longlong),
+                ("K", _I), ("sym_N", _I)]
+
+
+class N2EBwdGroup(ctypes.Structure):     # gn_n2e_bwd_group_t
+    _fields_ = [("xp", _P), ("pq", _P), ("H", _P), ("w2", _P), ("b2", _P), ("dedges", _P), ("dxp", _P), ("dpq", _P),
+                ("dw2", _P), ("db2", _P), ("E", _I), ("sym", _I)]
+
+
 class GemmDesc(ctypes.Structure):      # gn_gemm_desc_t
     _fields_ = [("A", _P), ("B", _P), ("C", _P), ("bias", _P), ("mask", _P), ("rs", _P), ("colsum", _P),
                 ("M", _I), ("N", _I), ("K", _I), ("lda", _I), ("ldb", _I), ("ldc", _I), ("ldmask", _I), ("rs_ld", _I),
@@ -120,6 +130,8 @@ SIGNATURES = {
     "gn_gumbel_ef_f32": (_I, [_P, _P, _P, ctypes.c_longlong, _I, _I, _I, _F, _I, _P]),
     "gn_gumbel_bwd_f32": (_I, [_P, _P, _P, _P, _P, ctypes.c_longlong, _I, _I, _F, _I, _P]),
     "gn_node2edge_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "gn_gumbel_bwd_grouped_f32": (_I, [ctypes.POINTER(GumbelBwdGroup), _I, _I, _F, _P]),
+    "gn_node2edge_bwd_grouped_f32": (_I, [ctypes.POINTER(N2EBwdGroup), _I, _I, _I, _P]),
     "gn_philox_uniform_f32": (_I, [_P, _SZ, _U64, _U64, _P, _P]),
     "gn_counter_add_u64": (_I, [_P, _U64, _P]),
 }

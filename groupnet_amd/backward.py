@@ -366,12 +366,14 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
             S = S_all
 
         # ---------------- back through the edge MLP + Gumbel softmax ----------------
-        for c in S:
+        # (one grouped launch for all modules: these launches take ~14 us whatever their size)
+        arr = (_lib.GumbelBwdGroup * len(S))()
+        for i, c in enumerate(S):
             c["dlgf"] = new(c["R"], _LGF_LD)
-            with torch.cuda.device(dev):
-                check(load().gn_gumbel_bwd_f32(_p(c["dist"]), _p(c["lgf"]), _p(c["def"]), _p(c["g_d"]), _p(c["dlgf"]),
-                                               c["R"], c["K"], _LGF_LD, _TAU, c["N"] if c["sym"] else 0, stream_handle()),
-                      "gn_gumbel_bwd_f32")
+            arr[i] = _lib.GumbelBwdGroup(_p(c["dist"]), _p(c["lgf"]), _p(c["def"]), _p(c["g_d"]), _p(c["dlgf"]), c["R"], c["K"],
+                                         c["N"] if c["sym"] else 0)
+        with torch.cuda.device(dev):
+            check(load().gn_gumbel_bwd_grouped_f32(arr, len(S), _LGF_LD, _TAU, stream_handle()), "gn_gumbel_bwd_grouped_f32")
 
         stage(lambda c: c.update(dd1=gb.add(c["dlgf"], c["tw"]["Wd1"], new(c["R"], 256), mask=c["dh1"])))
         stage(lambda c: c.update(dz=gb.add(c["dd1"], c["tw"]["Wd0"], new(c["R"], D))))
@@ -382,12 +384,27 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
             pool, BN = c["pool"], c["B"] * c["N"]
             c["dxp"], c["dpq"] = pool.take(BN, D), pool.take(BN, D)
             grads[c["a1"].weight], grads[c["a1"].bias] = pool.take(1, 32), pool.take(1)
+        N0 = S[0]["N"]
+        scene_form = (4 * N0 * D + 64 + 16 * N0) * 4 <= 150 * 1024 and all(c["B"] == S[0]["B"] and c["N"] == N0 for c in S)
+        if scene_form:
+            # every module in one launch (blockIdx.y = module): the pairwise module's 88 us and the hyper modules' 24-41 us
+            # side by side instead of end to end
+            arr = (_lib.N2EBwdGroup * len(S))()
+            for i, c in enumerate(S):
+                arr[i] = _lib.N2EBwdGroup(_p(c["xp"]), _p(c["pq"]), _p(c["H"]), _p(c["w2"]), _p(c["b2"]), _p(c["dedges"]),
+                                          _p(c["dxp"]), _p(c["dpq"]), _p(grads[c["a1"].weight]), _p(grads[c["a1"].bias]),
+                                          c["E"], int(c["sym"]))
             with torch.cuda.device(dev):
-                check(load().gn_node2edge_bwd_f32(_p(c["xp"]), _p(c["pq"]), _p(c["H"]), _p(c["w2"]), _p(c["b2"]),
-                                                  _p(c["dedges"]), _p(c["dxp"]), _p(c["dpq"]), _p(grads[c["a1"].weight]),
-                                                  _p(grads[c["a1"].bias]), c["B"], c["N"], c["E"], int(c["sym"]),
-                                                  stream_handle()),
-                      "gn_node2edge_bwd_f32")
+                check(load().gn_node2edge_bwd_grouped_f32(arr, len(S), S[0]["B"], N0, stream_handle()),
+                      "gn_node2edge_bwd_grouped_f32")
+        else:
+            for c in S:
+                with torch.cuda.device(dev):
+                    check(load().gn_node2edge_bwd_f32(_p(c["xp"]), _p(c["pq"]), _p(c["H"]), _p(c["w2"]), _p(c["b2"]),
+                                                      _p(c["dedges"]), _p(c["dxp"]), _p(c["dpq"]), _p(grads[c["a1"].weight]),
+                                                      _p(grads[c["a1"].bias]), c["B"], c["N"], c["E"], int(c["sym"]),
+                                                      stream_handle()),
+                          "gn_node2edge_bwd_f32")
         stage(lambda c: gb.add(c["dpq"], c["tw"]["Wpq"], c["dxp"], beta=1.0))
         stage(lambda c: c.update(dx1=gb.add(c["dxp"], W(c["s1"]), new(c["B"] * c["N"], 256), mask=c["x1"])))
 

@@ -383,10 +383,10 @@ __global__ __launch_bounds__(kB) void scale_kernel(float* __restrict__ C, long l
 // column K <- df, the rest 0.  sym_N > 0: rows are the unordered pairs of the pairwise graph — one row of
 // logits fed the two ordered edges (i,j), (j,i) of dist (each with its own noise), def is the gradient of
 // ef_ij + ef_ji, and the row receives the sum over its ordered edges.
-__global__ __launch_bounds__(kB) void gumbel_bwd_kernel(const float* __restrict__ dist, const float* __restrict__ lgf,
-                                                        const float* __restrict__ def, const float* __restrict__ gdist,
-                                                        float* __restrict__ dlgf, long long rows, int K, int ldl,
-                                                        float tau, int sym_N) {
+__device__ __forceinline__ void gumbel_bwd_body(const float* __restrict__ dist, const float* __restrict__ lgf,
+                                                const float* __restrict__ def, const float* __restrict__ gdist,
+                                                float* __restrict__ dlgf, long long rows, int K, int ldl, float tau,
+                                                int sym_N) {
   const int P = sym_N > 0 ? gn_pair_count(sym_N) : 1;
   for (long long r = (long long)blockIdx.x * kB + threadIdx.x; r < rows; r += (long long)gridDim.x * kB) {
     const float f = lgf[r * ldl + K];
@@ -420,6 +420,20 @@ __global__ __launch_bounds__(kB) void gumbel_bwd_kernel(const float* __restrict_
     }
     dlgf[r * ldl + K] = df;
   }
+}
+__global__ __launch_bounds__(kB) void gumbel_bwd_kernel(const float* __restrict__ dist, const float* __restrict__ lgf,
+                                                        const float* __restrict__ def, const float* __restrict__ gdist,
+                                                        float* __restrict__ dlgf, long long rows, int K, int ldl,
+                                                        float tau, int sym_N) {
+  gumbel_bwd_body(dist, lgf, def, gdist, dlgf, rows, K, ldl, tau, sym_N);
+}
+// every module of a backward stage in one launch (blockIdx.y = module): these launches take ~14 us whatever their size
+struct GumbelBwdTable {
+  gn_gumbel_bwd_group_t g[GN_MAX_GROUPS];
+};
+__global__ __launch_bounds__(kB) void gumbel_bwd_grouped_kernel(GumbelBwdTable T, int ldl, float tau) {
+  const gn_gumbel_bwd_group_t G = T.g[blockIdx.y];
+  gumbel_bwd_body(G.dist, G.lgf, G.def, G.gdist, G.dlgf, G.rows, G.K, ldl, tau, G.sym_N);
 }
 
 // Back through node2edge (one wave per hyperedge; forward quantities recomputed exactly as the forward
@@ -529,11 +543,11 @@ __global__ __launch_bounds__(kB) void node2edge_bwd_kernel(const float* __restri
 // 33 attention-layer-1 sums per scene.  H == nullptr selects the implicit pairwise graph (E = N*N, edge
 // e = i*N + j joins i and j with weight 1, weight 2 on i when i == j; model/MS_HGNN_batch.py:143-160), or
 // with sym its N(N+1)/2 unordered pairs (the two ordered edges of a pair pool the same feature).
-__global__ __launch_bounds__(kB) void node2edge_bwd_scene_kernel(
+__device__ __forceinline__ void node2edge_bwd_scene_body(
     const float* __restrict__ xp, const float* __restrict__ pq, const float* __restrict__ H,
     const float* __restrict__ w2, const float* __restrict__ b2p, const float* __restrict__ dedges,
     float* __restrict__ dxp,
-    float* __restrict__ dpq, float* __restrict__ dw2, float* __restrict__ db2, int N, int E, int sym) {
+    float* __restrict__ dpq, float* __restrict__ dw2, float* __restrict__ db2, int N, int E, int sym, const int b) {
   extern __shared__ __align__(16) float lds[];
   const float b2 = *b2p;
   const int NF = N * GN_FEAT;
@@ -549,7 +563,6 @@ __global__ __launch_bounds__(kB) void node2edge_bwd_scene_kernel(
   float* s_h = base + N;
   float* s_att = base + 2 * N;
   float* s_dw = base + 3 * N;
-  const int b = blockIdx.x;
   const float* xpb = xp + (size_t)b * NF;
   const float* pqb = pq + (size_t)b * NF;
   for (int i = threadIdx.x; i < NF; i += kB) {
@@ -659,6 +672,22 @@ __global__ __launch_bounds__(kB) void node2edge_bwd_scene_kernel(
   }
   if (threadIdx.x < 32) atomicAdd(dw2 + threadIdx.x, s_red[threadIdx.x]);
   if (threadIdx.x == 32) atomicAdd(db2, s_red[32]);
+}
+__global__ __launch_bounds__(kB) void node2edge_bwd_scene_kernel(
+    const float* __restrict__ xp, const float* __restrict__ pq, const float* __restrict__ H,
+    const float* __restrict__ w2, const float* __restrict__ b2p, const float* __restrict__ dedges,
+    float* __restrict__ dxp, float* __restrict__ dpq, float* __restrict__ dw2, float* __restrict__ db2, int N, int E,
+    int sym) {
+  node2edge_bwd_scene_body(xp, pq, H, w2, b2p, dedges, dxp, dpq, dw2, db2, N, E, sym, (int)blockIdx.x);
+}
+// every module of the stage in one launch: blockIdx.y = module, blockIdx.x = scene (the pairwise module's 88 us and the
+// hyper modules' 24-41 us side by side instead of end to end)
+struct N2EBwdTable {
+  gn_n2e_bwd_group_t g[GN_MAX_GROUPS];
+};
+__global__ __launch_bounds__(kB) void node2edge_bwd_scene_grouped_kernel(N2EBwdTable T, int N) {
+  const gn_n2e_bwd_group_t G = T.g[blockIdx.y];
+  node2edge_bwd_scene_body(G.xp, G.pq, G.H, G.w2, G.b2, G.dedges, G.dxp, G.dpq, G.dw2, G.db2, N, G.E, G.sym, (int)blockIdx.x);
 }
 
 // out[r][c] = alpha * a[r][c] + beta * out[r][c] on (rows x cols) blocks with leading dimensions
@@ -856,6 +885,47 @@ extern "C" int gn_node2edge_bwd_f32(const float* xp, const float* pq, const floa
   if (grid > 0x7fffffffLL) return GN_ERR_SHAPE;
   hipLaunchKernelGGL(node2edge_bwd_kernel, dim3((unsigned)grid), dim3(kB), lds, (hipStream_t)stream, xp, pq, H, w2, b2,
                      dedges, dxp, dpq, dw2, db2, N, E, total);
+  return gn_check_launch();
+}
+
+extern "C" int gn_gumbel_bwd_grouped_f32(const gn_gumbel_bwd_group_t* groups, int n_groups, int ldl, float tau,
+                                         gn_stream_t stream) {
+  if (groups == nullptr) return GN_ERR_NULL;
+  if (n_groups < 1 || n_groups > GN_MAX_GROUPS || !(tau > 0.f)) return GN_ERR_SHAPE;
+  GumbelBwdTable T{};
+  long long max_rows = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_gumbel_bwd_group_t& G = groups[g];
+    if (!G.dist || !G.lgf || !G.def || !G.dlgf) return GN_ERR_NULL;
+    if (G.rows <= 0 || G.K < 1 || ldl <= G.K || G.sym_N < 0) return GN_ERR_SHAPE;
+    if (G.sym_N > 0 && G.rows % gn_pair_count(G.sym_N) != 0) return GN_ERR_SHAPE;
+    T.g[g] = G;
+    max_rows = G.rows > max_rows ? G.rows : max_rows;
+  }
+  hipLaunchKernelGGL(gumbel_bwd_grouped_kernel, dim3(cap_grid(max_rows, kB), n_groups), dim3(kB), 0, (hipStream_t)stream, T,
+                     ldl, tau);
+  return gn_check_launch();
+}
+
+extern "C" int gn_node2edge_bwd_grouped_f32(const gn_n2e_bwd_group_t* groups, int n_groups, int B, int N,
+                                            gn_stream_t stream) {
+  if (groups == nullptr) return GN_ERR_NULL;
+  if (n_groups < 1 || n_groups > GN_MAX_GROUPS || B <= 0 || N <= 0) return GN_ERR_SHAPE;
+  const size_t scene_lds = ((size_t)4 * N * GN_FEAT + 64 + (size_t)(kB / 64) * 4 * N) * sizeof(float);
+  if (scene_lds > 150 * 1024) return GN_ERR_LDS;      // (the per-scene form only: larger N goes module by module)
+  N2EBwdTable T{};
+  for (int g = 0; g < n_groups; ++g) {
+    const gn_n2e_bwd_group_t& G = groups[g];
+    const void* ptrs[] = {G.xp, G.pq, G.w2, G.b2, G.dedges, G.dxp, G.dpq, G.dw2, G.db2};
+    for (const void* p : ptrs)
+      if (p == nullptr) return GN_ERR_NULL;
+    if (G.E <= 0 || (G.sym && G.H != nullptr)) return GN_ERR_SHAPE;
+    if (G.H == nullptr && G.E != (G.sym ? gn_pair_count(N) : N * N)) return GN_ERR_SHAPE;
+    T.g[g] = G;
+  }
+  if (scene_lds > 64 * 1024) gn_allow_big_lds(node2edge_bwd_scene_grouped_kernel);
+  hipLaunchKernelGGL(node2edge_bwd_scene_grouped_kernel, dim3((unsigned)B, n_groups), dim3(kB), scene_lds,
+                     (hipStream_t)stream, T, N);
   return gn_check_launch();
 }
 

@@ -463,6 +463,36 @@ int gn_typed_bwd_f32(float* T, const float* Hc, const float* ef, int ld_ef, cons
                      float* def, long long rows, int K, int hid, gn_stream_t stream);
 int gn_gumbel_bwd_f32(const float* dist, const float* lgf, const float* def, const float* gdist, float* dlgf,
                       long long rows, int K, int ldl, float tau, int sym_N, gn_stream_t stream);
+/* The two per-module stages above for every module of a backward round in ONE launch each (descriptor arrays in HOST
+ * memory, 1 <= n_groups <= GN_MAX_GROUPS; all modules over the same B scenes and N nodes): the single-module launches
+ * take 13-88 us each and ran end to end, four per stage and training step.  gn_node2edge_bwd_grouped_f32 covers the
+ * per-scene form only (the scene's rows fit in LDS, else GN_ERR_LDS: go module by module). */
+typedef struct {
+  const float* dist;
+  const float* lgf;
+  const float* def;
+  const float* gdist;   /* or NULL */
+  float* dlgf;
+  long long rows;
+  int K;
+  int sym_N;
+} gn_gumbel_bwd_group_t;
+int gn_gumbel_bwd_grouped_f32(const gn_gumbel_bwd_group_t* groups, int n_groups, int ldl, float tau, gn_stream_t stream);
+typedef struct {
+  const float* xp;
+  const float* pq;
+  const float* H;       /* or NULL: the pairwise graph */
+  const float* w2;
+  const float* b2;
+  const float* dedges;
+  float* dxp;
+  float* dpq;
+  float* dw2;
+  float* db2;
+  int E;
+  int sym;
+} gn_n2e_bwd_group_t;
+int gn_node2edge_bwd_grouped_f32(const gn_n2e_bwd_group_t* groups, int n_groups, int B, int N, gn_stream_t stream);
 int gn_node2edge_bwd_f32(const float* xp, const float* pq, const float* H, const float* w2, const float* b2,
                          const float* dedges, float* dxp, float* dpq, float* dw2, float* db2, int B, int N,
                          int E, int sym, gn_stream_t stream);
