@@ -137,8 +137,9 @@ class _Pool:
     """Zero-initialised scratch handed out in slices: every accumulate-by-atomics target of a round comes
     from one fill instead of one fill each."""
 
-    def __init__(self, numel: int, device):
-        self.buf = torch.zeros(numel, dtype=torch.float32, device=device)
+    def __init__(self, numel: int, device, buf: Optional[Tensor] = None):
+        # (buf: a zeroed slice of a larger fill — the modules of a round share ONE fill)
+        self.buf = torch.zeros(numel, dtype=torch.float32, device=device) if buf is None else buf
         self.used = 0
 
     def take(self, *shape: int) -> Tensor:
@@ -259,8 +260,14 @@ def round_backward(traces: Sequence[ModuleTrace], j: int, g_ys: Sequence[Optiona
                       f=st.MLP_factor.layers, agg=agg, tw=_bwd_weights(mod, j), e0=e0, e1=e1,
                       tail=t.tails[j], dist=t.dists[j].reshape(-1, K), g_y=None if g_y is None else g_y.reshape(B * N, -1).contiguous(),
                       g_d=None if g_d is None else g_d.reshape(-1, K).contiguous(),
-                      pool=_Pool(npar + 2 * B * N * D + B * E * (2 * K + 4 + 2 * D) + 4096, x.device)))
+                      pool_n=(npar + 2 * B * N * D + B * E * (2 * K + 4 + 2 * D) + 4096 + 63) // 64 * 64))
     dev = S[0]["x"].device
+    # one zero fill for the accumulate-by-atomics targets of every module of the round
+    arena = torch.zeros(sum(c["pool_n"] for c in S), dtype=torch.float32, device=dev)
+    off = 0
+    for c in S:
+        c["pool"] = _Pool(c["pool_n"], dev, arena[off:off + c["pool_n"]])
+        off += c["pool_n"]
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     gb = GemmBatch()
 
