@@ -1001,10 +1001,11 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
 // Stream order per type as everywhere (A0 A1 B0 A2 B1 A3 B2 B3, 8 sub-steps = one chunk per pair); V_t (scale,
 // convert, ReLU of hidden tile t) runs in the shadow of the MFMA group that precedes B_t: A_{t+1}, or B_2 for t = 3.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void agg_rb2_kernel(GroupTable<AggGroup> Tb) {
+__global__ __launch_bounds__(256, 2) void agg_rb2_kernel(GroupTable<AggGroup> Tb, int stage_bytes) {
   constexpr int RB = 2;
   using WS = WStream<1, 2>;
   __shared__ f32x4 wring[WS::kRingF4];
+  extern __shared__ __align__(16) unsigned char ori_dyn[];      // staged ori rows of the pairwise gather
   const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
   if (lwg < 0) return;
   const int gi = find_group(Tb, lwg);
@@ -1018,6 +1019,16 @@ __global__ __launch_bounds__(256, 2) void agg_rb2_kernel(GroupTable<AggGroup> Tb
   for (int b = 0; b < RB; ++b) rb[b] = row_block(rows, blk0 + b);   // (a block past the rows: clamped loads, no stores)
   WS ws;
   ws.begin(G.W12x, wring, lane, wave, K * 32 / WS::CH);
+  // pairwise gather (unordered pairs): the scenes' ori rows from an LDS stage when they fit (block-uniform)
+  const int nodes_max = (G.eo == nullptr && G.H == nullptr && G.sym) ? pool_stage_nodes(128 * RB, G.E, G.N) : 0;
+  const bool staged = nodes_max > 0 && (size_t)nodes_max * PoolStage<T>::kPitch * sizeof(T) <= (size_t)stage_bytes;
+  T* s_ori = reinterpret_cast<T*>(ori_dyn);
+  int node0 = 0;
+  if (staged) {
+    const int r0 = (lwg - Tb.first_wg[gi]) * (128 * RB);
+    node0 = ori_stage_fill<T>(G, r0, min(rows - 1, r0 + 128 * RB - 1), s_ori);
+    __syncthreads();
+  }
   Parts<1> xi[RB][2][2];
   const float* efrow[RB];
   f32x16 out[RB][2];
@@ -1026,6 +1037,8 @@ __global__ __launch_bounds__(256, 2) void agg_rb2_kernel(GroupTable<AggGroup> Tb
     f32x16 in[2];
     if (G.eo != nullptr)
       load_rows<2>(reinterpret_cast<const T*>(G.eo), GN_FEAT, rb[b].row_ld, h, in);
+    else if (staged)
+      gather_pair_staged<T>(G, rb[b].row_ld, h, s_ori, node0, in);
     else
       gather_rows<T>(G, rb[b].row_ld, h, in);
     make_parts_tiles<1, 2>(in, xi[b]);

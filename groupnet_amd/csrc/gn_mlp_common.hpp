@@ -602,6 +602,35 @@ __device__ __forceinline__ void gather_rows(const gn_agg_group_t& G, int row, in
   }
 }
 
+// The same stage for the typed MLP's pairwise gather (eo = ori_i + ori_j, bf16-storage twin): the scenes' ori rows once
+// per workgroup, coalesced; a row's two member rows then come from LDS.  Same operations as gather_rows: identical bits.
+template <typename T>
+__device__ __forceinline__ int ori_stage_fill(const gn_agg_group_t& G, int r0, int r1, T* __restrict__ s_ori) {
+  using PS = PoolStage<T>;
+  const int N = G.N, E = G.E;
+  const int b0 = r0 / E, b1 = r1 / E;
+  const int node0 = b0 * N, nodes = (b1 - b0 + 1) * N;
+  const T* src = reinterpret_cast<const T*>(G.ori) + (size_t)node0 * GN_FEAT;
+  for (int idx = threadIdx.x; idx < nodes * PS::kRowPieces; idx += blockDim.x) {
+    const int r = idx / PS::kRowPieces, c = idx - r * PS::kRowPieces;
+    *reinterpret_cast<f32x4*>(s_ori + r * PS::kPitch + c * PS::kPiece) =
+        *reinterpret_cast<const f32x4*>(src + (size_t)idx * PS::kPiece);
+  }
+  return node0;
+}
+template <typename T>
+__device__ __forceinline__ void gather_pair_staged(const gn_agg_group_t& G, int row, int h, const T* __restrict__ s_ori,
+                                                   int node0, f32x16 (&a)[2]) {
+  using PS = PoolStage<T>;
+  const int E = G.E, N = G.N;
+  const int b = row / E, e = row - b * E;
+  int i, j;
+  gn_pair_decode(e, N, i, j);
+  const T* ob = s_ori + (size_t)(b * N - node0) * PS::kPitch;
+  load_rows<2>(ob, PS::kPitch, i, h, a);                 // ori_i
+  add_row(ob + (size_t)j * PS::kPitch, 1.f, h, a);       // + ori_j  (2 ori_i on the diagonal)
+}
+
 __device__ __forceinline__ void relu_scale16(f32x16& a, float w) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f) * w;

@@ -1101,7 +1101,16 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
         wg += ((T.g[g].a.rows + 31) / 32 + 7) / 8;
       }
       T.first_wg[n_groups] = wg;
-      hipLaunchKernelGGL((agg_rb2_kernel<__bf16>), dim3(table_xcd_grid(T)), dim3(256), 0, stream, T);
+      // LDS for the staged ori rows of the pairwise gather (GN_POOL_STAGE = 0 switches it off)
+      static const bool no_stage = getenv("GN_POOL_STAGE") != nullptr && atoi(getenv("GN_POOL_STAGE")) == 0;
+      size_t sb = 0;
+      for (int g = 0; g < n_groups && !no_stage; ++g) {
+        const gn_agg_group_t& a = T.g[g].a;
+        if (a.eo != nullptr || a.H != nullptr || !a.sym) continue;
+        const size_t b = (size_t)pool_stage_nodes(256, a.E, a.N) * PoolStage<__bf16>::kPitch * sizeof(__bf16);
+        if (b <= 48 * 1024 && b > sb) sb = b;
+      }
+      hipLaunchKernelGGL((agg_rb2_kernel<__bf16>), dim3(table_xcd_grid(T)), dim3(256), sb, stream, T, (int)sb);
       return gn_check_launch();
     }
   }

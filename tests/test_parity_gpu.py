@@ -1086,6 +1086,7 @@ def test_staged_pairwise_pooling_is_bit_identical(dtype, B, N, scales, monkeypat
             monkeypatch.setenv("GN_POOL_STAGE", st)
             if dtype == torch.bfloat16:
                 monkeypatch.setenv("GN_EDGE_RB2", "1")
+                monkeypatch.setenv("GN_AGG_RB2", "1")     # (its pairwise gather ori_i + ori_j has the same stage)
             outs[st] = blk(f, noise_u=U)
             _, fac = blk.interaction(f, noise_u=U[0])
             outs[st] = (*outs[st], fac)
