@@ -218,6 +218,24 @@ def cpu_baseline(block_state, cfg, budget_s=20.0):
                        f"reference executes")
 
 
+def self_launch(n_gpus, port, dry):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>` as a CHILD process and return its exit
+    code.  The parent never initialises the GPU; the children's stdout (rank 0 prints the one JSON line) and stderr
+    pass straight through."""
+    import subprocess
+    from groupnet_amd.timing import launch_argv
+    passed = [a for a in sys.argv[1:] if a != "--dry-launch"]
+    argv = launch_argv(n_gpus, os.path.abspath(__file__), passed, port)
+    if dry:
+        print(json.dumps({"launch": argv}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(argv, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,17 +252,22 @@ def main():
     ap.add_argument("--no-train-leg", action="store_true", help="skip the training-step side measurement")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the multi-GPU code path (process group, bucketed all-gather) with one rank")
+    ap.add_argument("--master-port", type=int, default=29533, help="rendezvous port of the self-launched N > 1 run")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="with --gpus N > 1 and no WORLD_SIZE: print the launch command (JSON) instead of running it")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     if args.batch_per_gpu:
         cfg["B"] = args.batch_per_gpu
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves — from THIS process, which has not touched the GPU
+        # (no exec, no re-launch after a HIP call) — relay the ranks' output (rank 0's JSON line) and exit with their code
+        sys.exit(self_launch(args.gpus, args.master_port, args.dry_launch))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 through torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: groupnet_amd has no CPU path")
@@ -259,6 +282,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from groupnet_amd import ops, sharding
+    from groupnet_amd.timing import RegionTimer
     from groupnet_amd.graphs import GraphedMultiScale
     from groupnet_amd.multiscale import MultiScaleHGNN
     import groupnet_amd as G
@@ -311,30 +335,14 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-        def timed_region(n_steps, stepper):
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(n_steps):
-                stepper()
-            fence()
-            el = time.perf_counter() - t0
-            if distributed:
-                t = torch.tensor([el], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the slowest rank's clock
-                el = float(t.item())
-            return el
-
+        # the timed-region protocol (fences, max-over-ranks clock, agreed region count): groupnet_amd/timing.py,
+        # rehearsed under gloo in tests/test_bench_control.py
+        timer = RegionTimer(fence, dist if distributed else None, dev)
         for _ in range(args.warmup):
             step()
-        regions = [timed_region(args.steps, step)]
         # short regions are repeated (same K steps each) and the median is reported; every rank takes the same count
-        n_regions = 1 if regions[0] >= 0.05 else min(25, max(3, int(0.25 / max(regions[0], 1e-4))) | 1)
-        if distributed:
-            t = torch.tensor([n_regions], device=dev)
-            dist.broadcast(t, 0)
-            n_regions = int(t.item())
-        while len(regions) < n_regions:
-            regions.append(timed_region(args.steps, step))
+        regions = timer.measure(args.steps, step)
+        n_regions = len(regions)
         elapsed = statistics.median(regions)
 
         # ---- the same K steps on ONE stream, back to back (what a caller with a dependency between steps sees) ----
@@ -345,8 +353,7 @@ def main():
         if not distributed:
             for _ in range(min(args.warmup, 10)):
                 step1()
-            r1 = [timed_region(args.steps, step1) for _ in range(n_regions)]
-            single = statistics.median(r1)
+            single = statistics.median(timer.measure(args.steps, step1, n_regions))
 
         # ---- roofline leg: instrumented eager pass (rank 0) ---------------------------------------------
         roof = agg = mfma_kernels = train = None

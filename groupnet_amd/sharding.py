@@ -193,10 +193,14 @@ class BucketedGather:
             bg.put(out)                             # copies into the bank; gathers when the bank is full
         bg.flush()                                  # a partial last bank is gathered too
         bg.wait()                                   # host-side join of the gather stream
-        bg.gathered(bank)                           # (world * slots, *local_shape): rank-major, slot-minor
+        g = bg.gathered(bank)                       # (world, slots, *local_shape); the caller's current stream is made
+        consume(g)                                  # to wait for that bank's gather, so it may be read right away
+        bg.release(bank)                            # ... and the NEXT gather into `bank` waits for this consumer
 
     Bank reuse is ordered by events: a step that writes slot i of a bank first waits for the gather that last read
-    that bank.  Works on CPU tensors with the gloo backend too (no streams there: everything is synchronous),
+    that bank; `gathered(bank)` orders the reader's stream behind the gather that wrote `out[bank]`, and a reader
+    that keeps the view beyond the next `slots` puts calls `release(bank)` when done so that the gather two banks
+    later does not overwrite it under its hands.  Works on CPU tensors with the gloo backend too (no streams there: everything is synchronous),
     which is how the logic is tested without GPUs."""
 
     def __init__(self, slots: int, local_shape: Sequence[int], device, dtype=torch.float32, group=None):
@@ -211,6 +215,7 @@ class BucketedGather:
         self.out = torch.empty((2, self.world * self.slots) + self.local_shape, dtype=dtype, device=self.device)
         self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.bank_free = [None, None]        # event: the gather that last read this bank has finished
+        self.consumed = [None, None]         # event: the last reader of out[bank] is done (release)
         self.ready = [None] * self.slots     # event: slot i of the current bank has been written
         self.k = 0                           # steps put so far
         self.count = [0, 0]                  # valid slots in the last gather of each bank
@@ -244,6 +249,9 @@ class BucketedGather:
                 for ev in self.ready[:count]:
                     if ev is not None:
                         self.stream.wait_event(ev)
+                if self.consumed[bank] is not None:          # a reader of the previous gather into this bank
+                    self.stream.wait_event(self.consumed[bank])
+                    self.consumed[bank] = None
                 dist.all_gather_into_tensor(dst, src, group=self.group)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
@@ -266,5 +274,15 @@ class BucketedGather:
             self.stream.synchronize()
 
     def gathered(self, bank: int) -> Tensor:
-        """(world, slots, *local_shape) view of the last gather of `bank`: [r, i] = rank r's step in slot i."""
+        """(world, slots, *local_shape) view of the last gather of `bank`: [r, i] = rank r's step in slot i.  The
+        caller's current stream waits for that gather (no host block)."""
+        if self.cuda and self.bank_free[bank] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.bank_free[bank])
         return self.out[bank].view((self.world, self.slots) + self.local_shape)
+
+    def release(self, bank: int) -> None:
+        """The caller's current stream is done reading `gathered(bank)`: the next gather into that bank waits for it."""
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.consumed[bank] = ev
