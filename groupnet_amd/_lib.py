@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -27,7 +27,7 @@ _U64 = ctypes.c_ulonglong
 
 class NodeGroup(ctypes.Structure):      # gn_node_group_t
     _fields_ = [("x", _P), ("W", _P), ("bias", _P), ("xp", _P), ("pq", _P), ("hid_out", _P), ("Wx", _P),
-                ("WAx", _P), ("bA", _P), ("A", _P), ("KA", _I)]
+                ("WAx", _P), ("bA", _P), ("A", _P), ("KA", _I), ("Wh", _P), ("WAh", _P)]
 
 
 class N2EGroup(ctypes.Structure):       # gn_n2e_group_t
@@ -38,7 +38,7 @@ class EdgeGroup(ctypes.Structure):      # gn_edge_group_t
     _fields_ = [("edges", _P), ("U", _P), ("W", _P), ("bias", _P), ("edge_feat", _P), ("dist", _P),
                 ("philox_offset", _U64), ("rows", _I), ("K", _I), ("sym_N", _I), ("keep_z1", _P), ("keep_z", _P),
                 ("keep_dh1", _P), ("keep_lgf", _P), ("Wx", _P), ("xp", _P), ("pq", _P), ("pool_H", _P), ("w2", _P),
-                ("b2", _P), ("pool_N", _I), ("pool_E", _I)]
+                ("b2", _P), ("pool_N", _I), ("pool_E", _I), ("Wh", _P)]
 
 
 class GatherGroup(ctypes.Structure):    # gn_gather_group_t
@@ -47,7 +47,8 @@ class GatherGroup(ctypes.Structure):    # gn_gather_group_t
 
 class AggGroup(ctypes.Structure):       # gn_agg_group_t
     _fields_ = [("eo", _P), ("edge_feat", _P), ("W", _P), ("b1", _P), ("b2", _P), ("feat", _P), ("rows", _I),
-                ("K", _I), ("ori", _P), ("H", _P), ("E", _I), ("N", _I), ("sym", _I), ("A", _P), ("W2x", _P), ("W12x", _P)]
+                ("K", _I), ("ori", _P), ("H", _P), ("E", _I), ("N", _I), ("sym", _I), ("A", _P), ("W2x", _P), ("W12x", _P),
+                ("W2h", _P), ("W12h", _P)]
 
 
 class ScatterGroup(ctypes.Structure):   # gn_scatter_group_t
@@ -56,7 +57,7 @@ class ScatterGroup(ctypes.Structure):   # gn_scatter_group_t
 
 class Mlp2Group(ctypes.Structure):      # gn_mlp2_group_t
     _fields_ = [("x", _P), ("W", _P), ("bias", _P), ("y", _P), ("feat", _P), ("H", _P), ("ori", _P), ("E", _I),
-                ("sym", _I), ("in_out", _P), ("hid_out", _P), ("Wx", _P)]
+                ("sym", _I), ("in_out", _P), ("hid_out", _P), ("Wx", _P), ("Wh", _P)]
 
 
 class BlockExtras(ctypes.Structure):    # gn_block_extras_t

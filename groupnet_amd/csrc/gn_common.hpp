@@ -126,7 +126,7 @@ __device__ __forceinline__ int gn_xcd_logical(const XcdSections& S, int p) {
 }
 // host: finish a table whose first[0..n] is filled; returns the grid size
 static inline int gn_xcd_grid(XcdSections& S) {
-  static const bool off = getenv("GN_XCD") != nullptr && atoi(getenv("GN_XCD")) == 0;
+  const bool off = getenv("GN_XCD") != nullptr && atoi(getenv("GN_XCD")) == 0;      // (per call: tests toggle it)
   const int total = S.first[S.n];
   S.enabled = (!off && S.n <= GN_MAX_SECTIONS && total >= 64) ? 1 : 0;
   if (!S.enabled) return total;

@@ -10,6 +10,18 @@
 //          w3x1 + w2x2 + w1x3 + w2x1 + w1x2 + w1x1.  As accurate as fp32 accumulation (2e-7 of max|result| at
 //          K = 256), six 8-pass MFMAs per k = 16 instead of eight 16-pass fp32 MFMAs.  These are what the
 //          *_f32 entry points run when a group carries the `Wx` image.
+//   P = 2, T = float  — fp32 results on the fp16 cores ("f16x3", the default of the *_f32 entry points since round 3).
+//          Every fp32 operand is x = xh + xl with two fp16 parts (11 + 11 significant bits, the remainder is exact in
+//          fp32); a product is the three significant part-products, smallest first: wh.xl + wl.xh + wh.xh, three
+//          v_mfma_f32_32x32x16_f16 per k = 16 — half the matrix work and half the splitting work of bf16x6 at the
+//          same accuracy (3e-7 of max|result| at K = 256, measured next to an fp32 fma chain's 5e-7:
+//          tools/microbench/mfma_rate_f16x3.hip; chain rate 380-390 vs 202-220 TFLOP/s fp32-equivalent).  fp16 has a
+//          NARROW exponent: an operand beyond 65504 would become inf.  Every value that is split is therefore also
+//          folded into a running maximum (v_max3_f32, 8 instructions per hidden tile), the workgroup votes at the end
+//          of the chain, and a workgroup that saw |operand| > 65000 (or whose weight image is flagged: a weight out of
+//          range) REPEATS its rows on the bf16x6 path of the same kernel (P = 3 below, full fp32 exponent range) and
+//          overwrites what it stored — never a wrong result, and no cost on data within range.  Operands below 2^-14
+//          lose their low part (fp16 subnormals): an ABSOLUTE error of 2^-25 per such operand, far below the 1e-5 gate.
 //   P = 1, T = __bf16 — the bf16 twins (BASELINE config 4): activations stored in HBM as bf16,
 //          weights rounded once to bf16, one MFMA per k = 16, fp32 accumulation, bias / ReLU / softmax in fp32;
 //          a layer's fp32 result is rounded to bf16 when it becomes the next layer's operand or is stored.
@@ -67,9 +79,15 @@ __device__ __forceinline__ bf16x8 cvt_half(const f32x16& v, int hf) {
   return __builtin_convertvector(h, bf16x8);
 }
 
-// bf16 operand(s) of half `hf` of a 32-feature fp32 tile held in a lane's 16 registers
+// operand part(s) of half `hf` of a 32-feature fp32 tile held in a lane's 16 registers.  P = 2 (two fp16 parts) also
+// folds |v| into `ovf`, the wave's running maximum of everything it has split (see the header: range vote).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float kF16Limit = 65000.f;      // an operand beyond this sends the workgroup to the bf16x6 path
+typedef unsigned long long ovf_t;         // lanes that have split a value beyond kF16Limit (wave-uniform, in SGPRs)
 template <int P>
-__device__ __forceinline__ void make_parts(const f32x16& v, int hf, Parts<P>& x) {
+__device__ __forceinline__ void make_parts(const f32x16& v, int hf, Parts<P>& x, ovf_t& ovf) {
 #ifdef GN_DIAG_NO_SPLIT      // diagnostic builds only: what the kernels take without the VALU splitting work
   for (int p = 0; p < P; ++p) {
     const f32x4 w = {v[8 * hf], v[8 * hf + 1], v[8 * hf + 2], v[8 * hf + 3]};
@@ -77,15 +95,38 @@ __device__ __forceinline__ void make_parts(const f32x16& v, int hf, Parts<P>& x)
   }
   return;
 #endif
+  if constexpr (P == 3) {
 #pragma unroll
-  for (int jj = 0; jj < 8; ++jj) {
-    if constexpr (P == 3) {
+    for (int jj = 0; jj < 8; ++jj) {
       __bf16 a, b, c;
       split3(v[8 * hf + jj], a, b, c);
       x.p[0][jj] = a;
       x.p[1][jj] = b;
       x.p[2][jj] = c;
     }
+  }
+  if constexpr (P == 2) {
+    f16x8 hi, lo;
+    // (`ovf` is a wave-uniform lane mask in SCALAR registers: v_cmp + s_or_b64 per half tile.  Kept as a running fp32
+    // maximum in a vector register instead, the one serial chain through every split of the kernel cost the node / edge
+    // kernels 240 / 500 bytes of scratch per lane.)
+    float m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = v[8 * hf + 2 * j], b = v[8 * hf + 2 * j + 1];
+      m[j] = __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b));
+      const f32x2 pr = {a, b};
+      const f16x2 hh = __builtin_convertvector(pr, f16x2);                                       // v_cvt_pk_f16_f32 (RNE)
+      const f32x2 rem = {a - (float)hh[0], b - (float)hh[1]};                                    // exact
+      const f16x2 ll = __builtin_convertvector(rem, f16x2);
+      hi[2 * j] = hh[0], hi[2 * j + 1] = hh[1];
+      lo[2 * j] = ll[0], lo[2 * j + 1] = ll[1];
+    }
+    x.p[0] = __builtin_bit_cast(bf16x8, hi);
+    x.p[1] = __builtin_bit_cast(bf16x8, lo);
+#ifndef GN_NO_OVF
+    ovf |= __builtin_amdgcn_ballot_w64(__builtin_fmaxf(__builtin_fmaxf(m[0], m[1]), __builtin_fmaxf(m[2], m[3])) > kF16Limit);
+#endif
   }
   if constexpr (P == 1) x.p[0] = cvt_half(v, hf);
 }
@@ -95,7 +136,6 @@ __device__ __forceinline__ void make_parts(const f32x16& v, int hf, Parts<P>& x)
 // the P = 1 kernels are bound by VALU issue, not by the matrix pipe.  Written pair by pair: clamping the whole
 // 8-vector as i16x8 makes the compiler scalarise the conversion (8 one-source conversions + 4 v_perm per half).
 typedef short i16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void make_parts_relu(const f32x16& v, int hf, Parts<1>& x) {
@@ -111,13 +151,45 @@ __device__ __forceinline__ void make_parts_relu(const f32x16& v, int hf, Parts<1
 }
 
 template <int P, int NT>
-__device__ __forceinline__ void make_parts_tiles(const f32x16 (&v)[NT], Parts<P> (&x)[NT][2]) {
+__device__ __forceinline__ void make_parts_tiles(const f32x16 (&v)[NT], Parts<P> (&x)[NT][2], ovf_t& ovf) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    make_parts<P>(v[t], 0, x[t][0]);
-    make_parts<P>(v[t], 1, x[t][1]);
+    make_parts<P>(v[t], 0, x[t][0], ovf);
+    make_parts<P>(v[t], 1, x[t][1], ovf);
   }
 }
+// MFMAs per sub-step
+template <int P>
+constexpr int kMfmaPerSub = P == 3 ? 6 : (P == 2 ? 3 : 1);
+
+// ---- range vote of the f16x3 path ---------------------------------------------------------------------------------
+// `body(parts, ovf)` runs a workgroup's whole chain with `parts` parts per operand.  P = 2: first on the fp16 cores; if
+// any wave of the workgroup split a value beyond the fp16 range (or the weight image is flagged) the workgroup runs
+// the same chain again on the bf16x6 path and overwrites its stores.  The vote is workgroup-wide because the waves of
+// a workgroup share one weight stream (and its barriers).  Every wave of the workgroup must return from `body`.
+template <int P, typename F>
+__device__ __forceinline__ void run_with_fallback(F body) {
+  ovf_t ovf = 0ull;
+  if constexpr (P == 2) {
+    body(std::integral_constant<int, 2>{}, ovf);
+    if (!__syncthreads_or(ovf != 0ull)) return;
+#ifndef GN_NO_FALLBACK       // (diagnostic builds: the fp16 path alone)
+    ovf = 0ull;
+    body(std::integral_constant<int, 3>{}, ovf);
+#endif
+  } else {
+    body(std::integral_constant<int, P>{}, ovf);
+  }
+}
+// The flag word behind an fp16 weight image of `substeps` sub-steps (gn_split_f16_f32 sets it when a weight does not
+// fit fp16): nonzero sends the workgroup to the bf16x6 path.
+__device__ __forceinline__ ovf_t image_flag(const void* image, int substeps) {
+  const int f = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(image) + (size_t)substeps * 2 * 1024);
+  return gn_uniform(f) != 0 ? ~0ull : 0ull;
+}
+// the image a group's chain walks with P parts (f16x3: `h`, bf16x6 / twins: `x`)
+template <int P>
+__device__ __forceinline__ const void* pick_image(const void* x, const void* h) { return P == 2 ? h : x; }
 
 // acc += W[sub-step] . x from the sub-step's P 16-byte operand pieces
 template <int P>
@@ -136,6 +208,12 @@ __device__ __forceinline__ void mfma_substep(const f32x4 (&w)[P], const Parts<P>
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x.p[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.p[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x.p[0], acc, 0, 0, 0);
+  } else if constexpr (P == 2) {
+    const f16x8 wh = __builtin_bit_cast(f16x8, w[0]), wl = __builtin_bit_cast(f16x8, w[1]);
+    const f16x8 xh = __builtin_bit_cast(f16x8, x.p[0]), xl = __builtin_bit_cast(f16x8, x.p[1]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
   } else {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[0]), x.p[0], acc, 0, 0, 0);
   }
@@ -147,7 +225,7 @@ __device__ __forceinline__ void mfma_substep(const f32x4 (&w)[P], const Parts<P>
 // A stream is a sequence of segments (e.g. one per edge type) of `seg` sub-steps at `cur`, followed by `nxt`.
 template <int P>
 struct XStream {
-  static constexpr int D = P == 3 ? 4 : 8;    // ring depth in sub-steps
+  static constexpr int D = P == 1 ? 8 : 4;    // ring depth in sub-steps
   static constexpr int CH = 1;                // (positions are given in sub-steps: c0 is ignored)
   f32x4 q[D][P];
   const f32x4* cur;     // this lane's pointer at sub-step 0 of the current segment
@@ -186,9 +264,9 @@ struct XStream {
 //                 chunk c+2+LOOK : global -> staging registers
 // Requirements: all 4 waves of the workgroup call begin / step / skip with identical arguments (no early exits);
 // segment lengths are multiples of CH * LOOK sub-steps wherever the chunk index is not a compile-time constant.
-template <int P, int LOOK_ = (P == 3 ? 2 : 4)>
+template <int P, int LOOK_ = (P == 1 ? 4 : 2)>
 struct WStream {
-  static constexpr int CH = P == 3 ? 4 : 8;      // sub-steps per chunk
+  static constexpr int CH = P == 1 ? 8 : 4;      // sub-steps per chunk
   static constexpr int LOOK = LOOK_;             // chunks between a piece's global load and its LDS write (the kernels
                                                  // with two row blocks per wave spend twice as long per chunk: 2)
   static constexpr int R = 3;                    // chunks in the LDS ring
@@ -196,7 +274,7 @@ struct WStream {
   static constexpr int PW = PIECES / 4;          // pieces each of the 4 waves stages per chunk
   static constexpr int kChunkF4 = PIECES * 64;   // f32x4 elements of a chunk
   static constexpr int kRingF4 = R * kChunkF4;   // ... of the ring (36 KiB / 24 KiB)
-  static constexpr int QD = P == 3 ? 2 : 4;      // operand registers: sub-steps read ahead of their MFMA + 1.  A P = 3
+  static constexpr int QD = P == 1 ? 4 : 2;      // operand registers: sub-steps read ahead of their MFMA + 1.  A P = 3
                                                  // sub-step is 192 cycles of matrix work — one ahead covers the LDS
                                                  // latency; a P = 1 sub-step is 32 cycles, so three ahead
   // Running state instead of index arithmetic per access (a P = 1 sub-step is ONE 32-cycle MFMA: a handful of
@@ -321,13 +399,17 @@ struct WStream {
 template <int P, int IT, int OT, int HT, bool PACKED_RELU = false, typename Stream, typename PostFn>
 __device__ __forceinline__ void layer_pair(Stream& ws, int c0, int s0, const Parts<P> (&xi)[IT][2],
                                            const f32x16& hid0, const float* __restrict__ b0, int h,
-                                           f32x16 (&out)[OT], PostFn post) {
+                                           f32x16 (&out)[OT], ovf_t& ovf, PostFn post) {
   constexpr int NA = 2 * IT, NB = 2 * OT;
-  constexpr int kMfma = NA * (P == 3 ? 6 : 1);                 // MFMAs of one A phase
+  constexpr int kMfma = NA * kMfmaPerSub<P>;                   // MFMAs of one A phase
 #ifndef GN_KVALU
 #define GN_KVALU 96
 #endif
-  constexpr int kValu = P == 3 ? (GN_KVALU + kMfma - 1) / kMfma : (40 + kMfma - 1) / kMfma;   // VALU slots per MFMA
+#ifndef GN_KVALU2
+#define GN_KVALU2 84
+#endif
+  // VALU slots per MFMA (V_t: ReLU / scale, the split into parts, the range maximum)
+  constexpr int kValu = ((P == 3 ? GN_KVALU : (P == 2 ? GN_KVALU2 : 40)) + kMfma - 1) / kMfma;
   int pos = s0;
   f32x16 hidn = hid0;
   f32x16 bias_n;
@@ -350,8 +432,8 @@ __device__ __forceinline__ void layer_pair(Stream& ws, int c0, int s0, const Par
       make_parts_relu(cur, 0, xh[0]);
       make_parts_relu(cur, 1, xh[1]);
     } else {
-      make_parts<P>(cur, 0, xh[0]);
-      make_parts<P>(cur, 1, xh[1]);
+      make_parts<P>(cur, 0, xh[0], ovf);
+      make_parts<P>(cur, 1, xh[1], ovf);
     }
     if (t + 1 < HT) {
 #pragma unroll
@@ -363,7 +445,7 @@ __device__ __forceinline__ void layer_pair(Stream& ws, int c0, int s0, const Par
       for (int i = 0; i < kMfma; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
         __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);      // VALU of V_t in its shadow
-        if ((i % (P == 3 ? 6 : 1)) == 0)          // the sub-step's operand reads (LDS) / ring refills (global)
+        if ((i % kMfmaPerSub<P>) == 0)            // the sub-step's operand reads (LDS) / ring refills (global)
           __builtin_amdgcn_sched_group_barrier(Stream::CH == 1 ? 0x020 : 0x100, P, 0);
       }
     }
@@ -405,9 +487,8 @@ struct NodeTable {
 constexpr int kATiles = GN_KATILES;
 
 template <int P, typename T>
-__global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
+__device__ __forceinline__ void node_stage_body(const NodeTable& Tb, f32x4* wring, ovf_t& ovf) {
   using WS = WStream<P>;
-  __shared__ f32x4 wring[WS::kRingF4];
   const int wave = wave_id();
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int wg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
@@ -423,7 +504,9 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
     const float* b0 = G.bias;
     const float* b1 = G.bias + 256;
     const float* bpq = G.bias + 320;
-    ws.begin(G.Wx, wring, lane, wave, 72 / WS::CH);
+    const void* img = pick_image<P>(G.Wx, G.Wh);
+    if constexpr (P == 2) ovf |= image_flag(img, 72);
+    ws.begin(img, wring, lane, wave, 72 / WS::CH);
     f32x16 in[2];
     load_rows<2>(reinterpret_cast<const T*>(G.x), GN_FEAT, rb.row_ld, h, in);
     const f32x16 hid0 = load_bias_tile(b0, h);
@@ -433,12 +516,12 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
     pq[0] = load_bias_tile(bpq, h);
     pq[1] = load_bias_tile(bpq + 32, h);
     Parts<P> xi[2][2];
-    make_parts_tiles<P, 2>(in, xi);
+    make_parts_tiles<P, 2>(in, xi, ovf);
     GN_STAMP(unit, 1);
     // image: the 64->256->64 pair in pipeline order (A_t = [W0(t,in0), W0(t,in1)], B_t = [W1(0,t), W1(1,t)]), then
     // [Wpq(0,in0), Wpq(0,in1), Wpq(1,in0), Wpq(1,in1)]
-    layer_pair<P, 2, 2, 8, P == 1>(ws, 0, 0, xi, hid0, b0, h, xp, [&](int t, f32x16& hid) {
-      if constexpr (P == 3) {
+    layer_pair<P, 2, 2, 8, P == 1>(ws, 0, 0, xi, hid0, b0, h, xp, ovf, [&](int t, f32x16& hid) {
+      if constexpr (P != 1) {
         relu16(hid);
         if (G.hid_out != nullptr && rb.live) store_tile(G.hid_out + (size_t)rb.row * 256 + 32 * t + 4 * h, hid);
       }
@@ -446,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
     GN_STAMP(unit, 2);
     store_rows<2>(reinterpret_cast<T*>(G.xp), GN_FEAT, rb.row, h, rb.live, xp);
     Parts<P> xq[2][2];
-    make_parts_tiles<P, 2>(xp, xq);
+    make_parts_tiles<P, 2>(xp, xq, ovf);
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -473,11 +556,13 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
   const int o0 = c * kATiles;
   const int nt = min(kATiles, OTA - o0);                 // a multiple of 4
   // 4 sub-steps per output tile; the stream of this workgroup starts at tile o0 of the image
-  ws.begin(reinterpret_cast<const f32x4*>(G.WAx) + (size_t)o0 * 4 * P * 64, wring, lane, wave, (OTA - o0) * 4 / WS::CH);
+  const void* imgA = pick_image<P>(G.WAx, G.WAh);
+  if constexpr (P == 2) ovf |= image_flag(imgA, OTA * 4);
+  ws.begin(reinterpret_cast<const f32x4*>(imgA) + (size_t)o0 * 4 * P * 64, wring, lane, wave, (OTA - o0) * 4 / WS::CH);
   f32x16 in[2];
   load_rows<2>(reinterpret_cast<const T*>(G.x), GN_FEAT, rb.row_ld, h, in);
   Parts<P> xi[2][2];
-  make_parts_tiles<P, 2>(in, xi);
+  make_parts_tiles<P, 2>(in, xi, ovf);
   GN_STAMP(unit, 1);
   const size_t ldA = (size_t)OTA * 32;
   T* arow = reinterpret_cast<T*>(G.A) + (size_t)rb.row * ldA + 4 * h;
@@ -497,16 +582,24 @@ __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
   GN_STAMP(unit, 4);
   GN_STAMP(unit, 9);
 }
+// largest weight ring of the precisions a kernel instantiation may run (P = 2 falls back to 3)
+template <int P>
+constexpr int kRingF4For = WStream<P == 2 ? 3 : P>::kRingF4;
+
+template <int P, typename T>
+__global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
+  __shared__ f32x4 wring[kRingF4For<P>];
+  run_with_fallback<P>([&](auto pc, ovf_t& ovf) { node_stage_body<decltype(pc)::value, T>(Tb, wring, ovf); });
+}
 
 // ---- A4: z = MLP(64->128->64); [dist|fac] heads; gumbel softmax; sigmoid -------------------------------------
 // Image (80 sub-steps), hidden-tile-major: per hidden tile t of init_MLP the tiles [Wi0(t,in0), Wi0(t,in1),
 // Wi1(0,t), Wi1(1,t)], then per hidden tile t of [Wd0] the tiles [Wd0(t,in0), Wd0(t,in1), Wd1(0,t)].
 template <int P, typename T>
-__global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void edge_x_kernel(GroupTable<gn_edge_group_t> Tb, float tau,
-                                                        unsigned long long seed,
-                                                        const unsigned long long* __restrict__ offset_dev, int pool_bytes) {
+__device__ __forceinline__ void edge_x_body(const GroupTable<gn_edge_group_t>& Tb, float tau, unsigned long long seed,
+                                            const unsigned long long* __restrict__ offset_dev, int pool_bytes,
+                                            f32x4* wring, ovf_t& ovf) {
   using WS = WStream<P>;
-  __shared__ f32x4 wring[WS::kRingF4];
   extern __shared__ __align__(16) unsigned char pool_dyn[];      // staged x' / pq rows of the pairwise pooling
   const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
   if (lwg < 0) return;
@@ -556,7 +649,9 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void edge_x_kernel(Gro
   const float* bd0 = G.bias + 192;
   const float* bd1 = G.bias + 448;
   WS ws;
-  ws.begin(G.Wx, wring, lane, wave_id(), 80 / WS::CH);
+  const void* img = pick_image<P>(G.Wx, G.Wh);
+  if constexpr (P == 2) ovf |= image_flag(img, 80);
+  ws.begin(img, wring, lane, wave_id(), 80 / WS::CH);
   const f32x16 hidA0 = load_bias_tile(bi0, h);
   const f32x16 hidB0 = load_bias_tile(bd0, h);
   z[0] = load_bias_tile(bi1, h);
@@ -564,21 +659,21 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void edge_x_kernel(Gro
   f32x16 lgv[1];
   lgv[0] = load_bias_tile(bd1, h);
   Parts<P> xi[2][2];
-  make_parts_tiles<P, 2>(in, xi);
+  make_parts_tiles<P, 2>(in, xi, ovf);
   GN_STAMP(unit, 1);
   // ---- pair A: 64 -> 128 -> 64, 4 hidden tiles x (4 + 4) sub-steps, pipeline order ----
-  layer_pair<P, 2, 2, 4, P == 1>(ws, 0, 0, xi, hidA0, bi0, h, z, [&](int t, f32x16& hid) {
-    if constexpr (P == 3) {
+  layer_pair<P, 2, 2, 4, P == 1>(ws, 0, 0, xi, hidA0, bi0, h, z, ovf, [&](int t, f32x16& hid) {
+    if constexpr (P != 1) {
       relu16(hid);
       if (G.keep_z1 != nullptr && rb.live) store_tile(G.keep_z1 + (size_t)rb.row * 128 + 32 * t + 4 * h, hid);
     }
   });
   GN_STAMP(unit, 2);
   if (G.keep_z != nullptr) store_rows<2>(G.keep_z, GN_FEAT, rb.row, h, rb.live, z);
-  make_parts_tiles<P, 2>(z, xi);
+  make_parts_tiles<P, 2>(z, xi, ovf);
   // ---- pair B: 64 -> 256 -> (logits | factor), 8 hidden tiles x (4 + 2) sub-steps, pipeline order ----
-  layer_pair<P, 2, 1, 8, P == 1>(ws, 0, 32, xi, hidB0, bd0, h, lgv, [&](int t, f32x16& hid) {
-    if constexpr (P == 3) {
+  layer_pair<P, 2, 1, 8, P == 1>(ws, 0, 32, xi, hidB0, bd0, h, lgv, ovf, [&](int t, f32x16& hid) {
+    if constexpr (P != 1) {
       relu16(hid);
       if (G.keep_dh1 != nullptr && rb.live) store_tile(G.keep_dh1 + (size_t)rb.row * 256 + 32 * t + 4 * h, hid);
     }
@@ -632,6 +727,15 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void edge_x_kernel(Gro
   GN_STAMP(unit, 4);
   GN_STAMP(unit, 9);
 }
+template <int P, typename T>
+__global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void edge_x_kernel(GroupTable<gn_edge_group_t> Tb, float tau,
+                                                        unsigned long long seed,
+                                                        const unsigned long long* __restrict__ offset_dev, int pool_bytes) {
+  __shared__ f32x4 wring[kRingF4For<P>];
+  run_with_fallback<P>([&](auto pc, ovf_t& ovf) {
+    edge_x_body<decltype(pc)::value, T>(Tb, tau, seed, offset_dev, pool_bytes, wring, ovf);
+  });
+}
 
 // ---- A5 typed MLP on the bf16 cores: feat = sum_k ef[:,k] * (W2k relu(W1k eo + b1k) + b2k) -----------------------
 // Same work shapes as agg_mlp_kernel (wpr waves share a row block, partial sums meet in LDS).  Forms:
@@ -651,10 +755,9 @@ __device__ __forceinline__ void add_b2(const float* __restrict__ b2k, float efk,
 
 constexpr int kAggPartBytes = 4 * 32 * (64 + 8) * 4;
 template <int P, typename T>
-__global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(GroupTable<AggGroup> Tb) {
+__device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4* wring, ovf_t& ovf) {
   using WS = WStream<P>;
   constexpr int CH = WS::CH;
-  __shared__ f32x4 wring[WS::kRingF4];
   // wpr > 1: [wave][register 0..31][lane]; staged pair form: 2 x node rows.  Dynamic: a launch whose groups all run one
   // wave per row block without the stage (the large bf16 configurations) passes 0 bytes and fits more workgroups per CU.
   extern __shared__ __align__(16) float part_dyn[];
@@ -692,7 +795,10 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
   GN_STAMP(unit, 8);
 
   bool pair_form = false;
-  if constexpr (P == 3) pair_form = G.A != nullptr;
+  if constexpr (P != 1) pair_form = G.A != nullptr;
+  // (the weight image of this group's form and its flag word)
+  const void* img = pair_form ? pick_image<P>(G.W2x, G.W2h) : pick_image<P>(G.W12x, G.W12h);
+  if constexpr (P == 2) ovf |= image_flag(img, pair_form ? K * 16 : K * 32);
   if (pair_form && wpr == 1) {
     // ---- pair form: hid_t = relu(A_i + A_j) * ef_k is VALU work (V_t), its layer-2 slice the matrix work (B_t:
     // one chunk of the stream, 16 sub-steps per type).  wpr == 1, pipelined: V of the NEXT tile (the next type's
@@ -711,15 +817,15 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
     }
     const size_t ldA = (size_t)K * 128;
     const T* Abase = reinterpret_cast<const T*>(G.A);
-    ws.begin(G.W2x, wring, lane, wave, K * 16 / CH);
+    ws.begin(img, wring, lane, wave, K * 16 / CH);
     auto hidden = [&](const PreTile& pa, const PreTile& pb, float efk, Parts<P> (&xh)[2]) {
       f32x16 hid;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c) hid[4 * q + c] = fmaxf(pa.v[q][c] + pb.v[q][c], 0.f) * efk;
-      make_parts<P>(hid, 0, xh[0]);
-      make_parts<P>(hid, 1, xh[1]);
+      make_parts<P>(hid, 0, xh[0], ovf);
+      make_parts<P>(hid, 1, xh[1], ovf);
     };
     // B_t with the next tile's V in its shadow
     auto slice = [&](int c0, int t, const Parts<P> (&xh)[2], PreTile& pa, PreTile& pb, float ef_next,
@@ -731,10 +837,10 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
       for (int u = 0; u < 4; ++u)                    // [W2(0,t) hf0, hf1, W2(1,t) hf0, hf1]
         ws.template step<false>(c0, 4 * t + u, xh[u & 1], out[u >> 1]);
 #pragma unroll
-      for (int m = 0; m < 24; ++m) {
+      for (int m = 0; m < 4 * kMfmaPerSub<P>; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-        if (m % 6 == 0) __builtin_amdgcn_sched_group_barrier(0x100, P, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, P == 2 ? 11 : 7, 0);
+        if (m % kMfmaPerSub<P> == 0) __builtin_amdgcn_sched_group_barrier(0x100, P, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -837,7 +943,7 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
       const size_t ldA = (size_t)K * 128;
       const T* Ai = reinterpret_cast<const T*>(G.A) + (size_t)i * ldA;
       const T* Aj = reinterpret_cast<const T*>(G.A) + (size_t)j * ldA;
-      const f32x4* Wx = reinterpret_cast<const f32x4*>(G.W2x) + lane;   // sub-step s of type k: (k*16 + s)
+      const f32x4* Wx = reinterpret_cast<const f32x4*>(img) + lane;     // sub-step s of type k: (k*16 + s)
       XStream<P> xs;
       xs.begin(Wx + (size_t)sub * 16 * P * 64);
 #pragma unroll 1
@@ -859,8 +965,8 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
             pb = load_pre(Aj + k * 128 + 32 * (t + 1), h);
           }
           Parts<P> xh[2];
-          make_parts<P>(hid, 0, xh[0]);
-          make_parts<P>(hid, 1, xh[1]);
+          make_parts<P>(hid, 0, xh[0], ovf);
+          make_parts<P>(hid, 1, xh[1], ovf);
 #pragma unroll
           for (int u = 0; u < 4; ++u) xs.step(0, 4 * t + u, xh[u & 1], out[u >> 1]);
         }
@@ -881,9 +987,9 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
       gather_rows<T>(G, rb.row_ld, h, in);
     }
     Parts<P> xi[2][2];
-    make_parts_tiles<P, 2>(in, xi);
+    make_parts_tiles<P, 2>(in, xi, ovf);
     GN_STAMP(unit, 1);
-    ws.begin(G.W12x, wring, lane, wave, K * 32 / CH);
+    ws.begin(img, wring, lane, wave, K * 32 / CH);
     f32x16 hid0 = load_bias_tile(b1, h);
     float efk = efrow[0];
 #pragma unroll 1
@@ -898,14 +1004,14 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
         f32x16 tmp[2];
         tmp[0] = load_bias_tile(b2 + k * 64, h);
         tmp[1] = load_bias_tile(b2 + k * 64 + 32, h);
-        layer_pair<P, 2, 2, 4, true>(ws, k * 32 / CH, 0, xi, hid0, b1 + k * 128, h, tmp, [&](int, f32x16&) {});
+        layer_pair<P, 2, 2, 4, true>(ws, k * 32 / CH, 0, xi, hid0, b1 + k * 128, h, tmp, ovf, [&](int, f32x16&) {});
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll
           for (int r = 0; r < 16; ++r) out[o][r] = fmaf(efk, tmp[o][r], out[o][r]);
       } else {
         add_b2(b2 + k * 64, efk, lane, h, out);
-        layer_pair<P, 2, 2, 4>(ws, k * 32 / CH, 0, xi, hid0, b1 + k * 128, h, out,
+        layer_pair<P, 2, 2, 4>(ws, k * 32 / CH, 0, xi, hid0, b1 + k * 128, h, out, ovf,
                                [&](int, f32x16& hid) { relu_scale16(hid, efk); });
       }
       hid0 = hid0_next;
@@ -925,9 +1031,9 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
       gather_rows<T>(G, rb.row_ld, h, in);
     }
     Parts<P> xi[2][2];
-    make_parts_tiles<P, 2>(in, xi);
+    make_parts_tiles<P, 2>(in, xi, ovf);
     GN_STAMP(unit, 1);
-    const f32x4* Wx = reinterpret_cast<const f32x4*>(G.W12x) + lane;   // sub-step s of type k: (k*32 + s)
+    const f32x4* Wx = reinterpret_cast<const f32x4*>(img) + lane;      // sub-step s of type k: (k*32 + s)
     XStream<P> xs;
     xs.begin(Wx + (size_t)sub * 32 * P * 64);
     f32x16 hid0 = load_bias_tile(b1 + sub * 128, h);
@@ -941,14 +1047,14 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
         f32x16 tmp[2];
         tmp[0] = load_bias_tile(b2 + k * 64, h);
         tmp[1] = load_bias_tile(b2 + k * 64 + 32, h);
-        layer_pair<P, 2, 2, 4, true>(xs, 0, 0, xi, hid0, b1 + k * 128, h, tmp, [&](int, f32x16&) {});
+        layer_pair<P, 2, 2, 4, true>(xs, 0, 0, xi, hid0, b1 + k * 128, h, tmp, ovf, [&](int, f32x16&) {});
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll
           for (int r = 0; r < 16; ++r) out[o][r] = fmaf(efk, tmp[o][r], out[o][r]);
       } else {
         add_b2(b2 + k * 64, efk, lane, h, out);
-        layer_pair<P, 2, 2, 4>(xs, 0, 0, xi, hid0, b1 + k * 128, h, out, [&](int, f32x16& hid) { relu_scale16(hid, efk); });
+        layer_pair<P, 2, 2, 4>(xs, 0, 0, xi, hid0, b1 + k * 128, h, out, ovf, [&](int, f32x16& hid) { relu_scale16(hid, efk); });
       }
       hid0 = hid0_next;
     }
@@ -988,6 +1094,11 @@ __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(Grou
   GN_STAMP(unit, 4);
   GN_STAMP(unit, 9);
 }
+template <int P, typename T>
+__global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(GroupTable<AggGroup> Tb) {
+  __shared__ f32x4 wring[kRingF4For<P>];
+  run_with_fallback<P>([&](auto pc, ovf_t& ovf) { agg_x_body<decltype(pc)::value, T>(Tb, wring, ovf); });
+}
 
 // ---- A5 typed MLP, bf16 storage, TWO row blocks per wave (large launches, one wave per row-block pair) --------------
 // A P = 1 sub-step is ONE 32-cycle MFMA against one 1-KiB weight operand: with one row block per wave the LDS operand
@@ -1004,6 +1115,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void agg_rb2_kernel(GroupTable<AggGroup> Tb, int stage_bytes) {
   constexpr int RB = 2;
   using WS = WStream<1, 2>;
+  ovf_t ovf_unused = 0ull;      // (the range vote belongs to the two-part fp16 path)
   __shared__ f32x4 wring[WS::kRingF4];
   extern __shared__ __align__(16) unsigned char ori_dyn[];      // staged ori rows of the pairwise gather
   const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
@@ -1041,7 +1153,7 @@ __global__ __launch_bounds__(256, 2) void agg_rb2_kernel(GroupTable<AggGroup> Tb
       gather_pair_staged<T>(G, rb[b].row_ld, h, s_ori, node0, in);
     else
       gather_rows<T>(G, rb[b].row_ld, h, in);
-    make_parts_tiles<1, 2>(in, xi[b]);
+    make_parts_tiles<1, 2>(in, xi[b], ovf_unused);
     efrow[b] = G.edge_feat + (size_t)rb[b].row_ld * K;
 #pragma unroll
     for (int o = 0; o < 2; ++o)
@@ -1151,6 +1263,7 @@ __global__ __launch_bounds__(256, 2) void edge_rb2_kernel(GroupTable<gn_edge_gro
                                                           const unsigned long long* __restrict__ offset_dev, int pool_bytes) {
   constexpr int RB = 2;
   using WS = WStream<1, 2>;
+  ovf_t ovf_unused = 0ull;      // (the range vote belongs to the two-part fp16 path)
   __shared__ f32x4 wring[WS::kRingF4];
   extern __shared__ __align__(16) unsigned char pool_dyn[];      // staged x' / pq rows of the pairwise pooling
   const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
@@ -1192,7 +1305,7 @@ __global__ __launch_bounds__(256, 2) void edge_rb2_kernel(GroupTable<gn_edge_gro
       pooled_rows_staged<T>(G, rb[b].row_ld, h, s_xp, s_pq, node0, in);
     else
       pooled_rows<T>(G, rb[b].row_ld, h, in);  // fused node -> edge pooling
-    make_parts_tiles<1, 2>(in, xi[b]);
+    make_parts_tiles<1, 2>(in, xi[b], ovf_unused);
   }
   f32x16 bias_n = load_bias_tile(bi0, h), bias_nn = load_bias_tile(bi0 + 32, h);
   f32x16 hidn[RB];
@@ -1257,7 +1370,7 @@ __global__ __launch_bounds__(256, 2) void edge_rb2_kernel(GroupTable<gn_edge_gro
     shadow();
     Bm(Fence{}, 28, xb);
 #pragma unroll
-    for (int b = 0; b < RB; ++b) make_parts_tiles<1, 2>(z[b], xi[b]);
+    for (int b = 0; b < RB; ++b) make_parts_tiles<1, 2>(z[b], xi[b], ovf_unused);
   }
   // ---- pair B: 64 -> 256 -> (logits | factor) (positions 32 .. 79: A_t 4 sub-steps, B_t 2) ----
   f32x16 lg[RB];
@@ -1387,10 +1500,9 @@ __global__ __launch_bounds__(256, 2) void edge_rb2_kernel(GroupTable<gn_edge_gro
 // (occupancy: the fused scatter of the three-part kernel keeps ~200 registers in flight — one workgroup per CU; the
 // bf16-storage kernel fits two with 128 inputs, three with 64)
 template <int P, typename T, int IT, int HT, int OT>
-__global__ __launch_bounds__(256, P == 1 ? (IT == 4 ? 2 : 3) : (IT == 4 ? 1 : 2)) void mlp2_x_kernel(GroupTable<gn_mlp2_group_t> Tb, int rows, int dout, int ldy,
-                                                        int N, float divisor) {
+__device__ __forceinline__ void mlp2_x_body(const GroupTable<gn_mlp2_group_t>& Tb, int rows, int dout, int ldy, int N,
+                                            float divisor, f32x4* wring, ovf_t& ovf) {
   using WS = WStream<P>;
-  __shared__ f32x4 wring[WS::kRingF4];
   const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
   if (lwg < 0) return;
   const int gi = find_group(Tb, lwg);             // (first_wg[g] = g * workgroups per group)
@@ -1416,13 +1528,15 @@ __global__ __launch_bounds__(256, P == 1 ? (IT == 4 ? 2 : 3) : (IT == 4 ? 1 : 2)
     // chunks of the weight stream arrive in their shadow
     f32x16 in[IT];
     mlp2_rows<IT, T>(G, rb.row_ld, h, N, divisor, in);
-    ws.begin(G.Wx, wring, lane, wave_id(), kSub / WS::CH);
+    const void* img = pick_image<P>(G.Wx, G.Wh);
+    if constexpr (P == 2) ovf |= image_flag(img, kSub);
+    ws.begin(img, wring, lane, wave_id(), kSub / WS::CH);
     if (G.in_out != nullptr) store_rows<IT>(G.in_out, 32 * IT, rb.row, h, rb.live, in);   // kept for the backward
-    make_parts_tiles<P, IT>(in, xi);
+    make_parts_tiles<P, IT>(in, xi, ovf);
   }
   GN_STAMP(unit, 1);
-  layer_pair<P, IT, OT, HT, P == 1>(ws, 0, 0, xi, hid0, b0, h, out, [&](int t, f32x16& hid) {
-    if constexpr (P == 3) {
+  layer_pair<P, IT, OT, HT, P == 1>(ws, 0, 0, xi, hid0, b0, h, out, ovf, [&](int t, f32x16& hid) {
+    if constexpr (P != 1) {
       relu16(hid);
       if (G.hid_out != nullptr && rb.live) store_tile(G.hid_out + (size_t)rb.row * (32 * HT) + 32 * t + 4 * h, hid);
     }
@@ -1434,6 +1548,14 @@ __global__ __launch_bounds__(256, P == 1 ? (IT == 4 ? 2 : 3) : (IT == 4 ? 1 : 2)
   }
   GN_STAMP(unit, 4);
   GN_STAMP(unit, 9);
+}
+template <int P, typename T, int IT, int HT, int OT>
+__global__ __launch_bounds__(256, P == 1 ? (IT == 4 ? 2 : 3) : (IT == 4 ? 1 : 2)) void mlp2_x_kernel(GroupTable<gn_mlp2_group_t> Tb, int rows, int dout, int ldy,
+                                                        int N, float divisor) {
+  __shared__ f32x4 wring[kRingF4For<P>];
+  run_with_fallback<P>([&](auto pc, ovf_t& ovf) {
+    mlp2_x_body<decltype(pc)::value, T, IT, HT, OT>(Tb, rows, dout, ldy, N, divisor, wring, ovf);
+  });
 }
 
 
@@ -1458,7 +1580,7 @@ __global__ __launch_bounds__(256, P == 1 ? (IT == 4 ? 2 : 3) : (IT == 4 ? 1 : 2)
 // a ring of D sub-steps refilled straight from L2.
 template <int P, int L>
 struct PStream {
-  static constexpr int D = P == 3 ? 4 : 8;
+  static constexpr int D = P == 1 ? 8 : 4;
   f32x4 q[D][P];
   template <typename AT>
   __device__ __forceinline__ void begin(AT at) {
@@ -1627,11 +1749,11 @@ __device__ __forceinline__ void read_tile_lines(const float* __restrict__ scratc
 
 // operand exchange through LDS: the bf16 part(s) of one input tile, lane-linear 16-byte pieces (conflict-free)
 template <int P>
-__device__ __forceinline__ void put_parts(f32x4* lds, int tile, int lane, const f32x16& v) {
+__device__ __forceinline__ void put_parts(f32x4* lds, int tile, int lane, const f32x16& v, ovf_t& ovf) {
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
     Parts<P> x;
-    make_parts<P>(v, hf, x);
+    make_parts<P>(v, hf, x, ovf);
 #pragma unroll
     for (int p = 0; p < P; ++p) lds[((tile * 2 + hf) * P + p) * 64 + lane] = __builtin_bit_cast(f32x4, x.p[p]);
   }
@@ -1671,14 +1793,13 @@ __device__ __forceinline__ f32x4 sum_partial(const f32x4* lds, int q, int lane) 
 
 // ---- closing MLP, 4 waves per row block: y = W1 relu(W0 x + b0) + b1, dout <= 64 ----------------------------------------
 // Same image, same inputs (incl. the fused scatter) and the same optional kept activations as mlp2_x_kernel.
+template <int P, int IT, int OT>
+constexpr int kXsLdsF4 = (IT * 2 * P * 64 > 4 * 4 * OT * 64) ? IT * 2 * P * 64 : 4 * 4 * OT * 64;
 template <int P, typename T, int IT, int HT, int OT>
-__global__ __launch_bounds__(256, HT == 4 ? 3 : 2) void mlp2_xs_kernel(GroupTable<gn_mlp2_group_t> Tb, int rows, int dout, int ldy, int N,
-                                                          float divisor) {
+__device__ __forceinline__ void mlp2_xs_body(const GroupTable<gn_mlp2_group_t>& Tb, int rows, int dout, int ldy, int N,
+                                             float divisor, f32x4* lds, float (*lines)[32 * kLinePitch], ovf_t& ovf) {
   static_assert(HT % 4 == 0, "hidden tiles are dealt over 4 waves");
   constexpr int TPW = HT / 4, NA = 2 * IT, NB = 2 * OT, L = TPW * (NA + NB);
-  constexpr int kXin = IT * 2 * P * 64, kPart = 4 * 4 * OT * 64;
-  __shared__ f32x4 lds[kXin > kPart ? kXin : kPart];
-  __shared__ __align__(16) float lines[2][32 * kLinePitch];     // layout change of the fused scatter (waves 0 / 1)
   const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
   if (lwg < 0) return;
   const int gi = find_group(Tb, lwg);
@@ -1691,7 +1812,9 @@ __global__ __launch_bounds__(256, HT == 4 ? 3 : 2) void mlp2_xs_kernel(GroupTabl
   GN_STAMP(unit, 8);
   const float* b0 = G.bias;
   const float* b1 = G.bias + 32 * HT;
-  const f32x4* img = reinterpret_cast<const f32x4*>(G.Wx) + lane;
+  const void* image = pick_image<P>(G.Wx, G.Wh);
+  if constexpr (P == 2) ovf |= image_flag(image, HT * (NA + NB));
+  const f32x4* img = reinterpret_cast<const f32x4*>(image) + lane;
   const f32x4* segA[TPW];
   const f32x4* segB[TPW];
 #pragma unroll
@@ -1720,7 +1843,7 @@ __global__ __launch_bounds__(256, HT == 4 ? 3 : 2) void mlp2_xs_kernel(GroupTabl
     else mlp2_rows_tile<T>(G, rb.row_ld, h, N, divisor, IT, wave, in);
     ps.begin(at);       // (behind the gather, whose batches of member rows need the registers; in flight across the exchange)
     if (G.in_out != nullptr && rb.live) store_tile(G.in_out + (size_t)rb.row * (32 * IT) + 32 * wave + 4 * h, in);
-    put_parts<P>(lds, wave, lane, in);
+    put_parts<P>(lds, wave, lane, in, ovf);
   } else {
     ps.begin(at);
   }
@@ -1771,8 +1894,8 @@ __global__ __launch_bounds__(256, HT == 4 ? 3 : 2) void mlp2_xs_kernel(GroupTabl
       relu16(hid[tt]);
       if (G.hid_out != nullptr && rb.live)
         store_tile(G.hid_out + (size_t)rb.row * (32 * HT) + 32 * (wave + 4 * tt) + 4 * h, hid[tt]);
-      make_parts<P>(hid[tt], 0, xh[0]);
-      make_parts<P>(hid[tt], 1, xh[1]);
+      make_parts<P>(hid[tt], 0, xh[0], ovf);
+      make_parts<P>(hid[tt], 1, xh[1], ovf);
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
@@ -1809,6 +1932,15 @@ __global__ __launch_bounds__(256, HT == 4 ? 3 : 2) void mlp2_xs_kernel(GroupTabl
         if (f + c < dout) st1(yrow + f + c, v[c]);
     }
   }
+}
+template <int P, typename T, int IT, int HT, int OT>
+__global__ __launch_bounds__(256, HT == 4 ? 3 : 2) void mlp2_xs_kernel(GroupTable<gn_mlp2_group_t> Tb, int rows, int dout, int ldy, int N,
+                                                          float divisor) {
+  __shared__ f32x4 lds[kXsLdsF4<P == 2 ? 3 : P, IT, OT>];
+  __shared__ __align__(16) float lines[2][32 * kLinePitch];     // layout change of the fused scatter (waves 0 / 1)
+  run_with_fallback<P>([&](auto pc, ovf_t& ovf) {
+    mlp2_xs_body<decltype(pc)::value, T, IT, HT, OT>(Tb, rows, dout, ldy, N, divisor, lds, lines, ovf);
+  });
 }
 
 }  // namespace

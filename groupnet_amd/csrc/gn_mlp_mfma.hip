@@ -87,9 +87,19 @@ __device__ __forceinline__ void split_bf16_image(const float* __restrict__ packe
     const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63), half = (int)((idx >> 9) & 1);
     const long long tile = idx >> 10;
     const float x = packed[tile * kTileFloats + (((j >> 2) + 2 * half) * 64 + lane) * 4 + (j & 3)];
+    __bf16* o = out + ((tile * 2 + half) * parts * 64 + lane) * 8 + j;
+    if (parts == 2) {
+      // f16x3 image: x = hi + lo, two fp16 parts (the remainder is exact in fp32).  A weight that does not fit fp16
+      // raises the flag word behind the image: its workgroups then take the bf16x6 path (gn_mlp_bf16.hpp).
+      const _Float16 hi = (_Float16)x;
+      const _Float16 lo = (_Float16)(x - (float)hi);
+      reinterpret_cast<_Float16*>(o)[0] = hi;
+      reinterpret_cast<_Float16*>(o)[64 * 8] = lo;
+      if (!(fabsf(x) <= 65000.f)) atomicOr(reinterpret_cast<int*>(out + (size_t)n_tiles * 2 * 2 * 64 * 8), 1);
+      continue;
+    }
     __bf16 p1, p2, p3;
     split3(x, p1, p2, p3);
-    __bf16* o = out + ((tile * 2 + half) * parts * 64 + lane) * 8 + j;
     o[0] = p1;
     if (parts == 3) {
       o[64 * 8] = p2;
@@ -829,7 +839,7 @@ extern "C" int gn_pack_linear_f32(const float* W, float* Wp, int out_features, i
 extern "C" int gn_split_bf16_f32(const float* packed, void* out, int n_tiles, int parts, gn_stream_t stream) {
   GN_REQUIRE_PTR(packed);
   GN_REQUIRE_PTR(out);
-  if (n_tiles < 1 || (parts != 1 && parts != 3)) return GN_ERR_SHAPE;
+  if (n_tiles < 1 || parts < 1 || parts > 3) return GN_ERR_SHAPE;
   GN_REQUIRE_ALIGNED(out);
   const long long total = (long long)n_tiles * 1024;
   hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)),
@@ -840,7 +850,7 @@ extern "C" int gn_split_bf16_f32(const float* packed, void* out, int n_tiles, in
 extern "C" int gn_split_bf16_batch_f32(const gn_split_job_t* jobs_dev, int n_jobs, int max_tiles, int parts,
                                        gn_stream_t stream) {
   GN_REQUIRE_PTR(jobs_dev);
-  if (n_jobs < 1 || n_jobs > 65535 || max_tiles < 1 || (parts != 1 && parts != 3)) return GN_ERR_SHAPE;
+  if (n_jobs < 1 || n_jobs > 65535 || max_tiles < 1 || parts < 1 || parts > 3) return GN_ERR_SHAPE;
   const long long total = (long long)max_tiles * 1024;
   const unsigned gx = (unsigned)((total + 255) / 256 < 256 ? (total + 255) / 256 : 256);
   hipLaunchKernelGGL(split_bf16_batch_kernel, dim3(gx, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, parts);
@@ -878,9 +888,11 @@ static int node_stage_launch(const gn_node_group_t* groups, int n_groups, int ro
     const void* ptrs[] = {G.x, G.Wx, G.bias, G.xp, G.pq};
     for (const void* p : ptrs) GN_CHECK(need(p, true));
     if (P == 1 && G.hid_out != nullptr) return GN_ERR_SHAPE;   // the twins are forward-only
+    if (P == 2) GN_CHECK(need(G.Wh, true));
     Tb.a_first[g] = a_wgs;
     if (G.A != nullptr) {
       GN_CHECK(need(G.WAx, true));
+      if (P == 2) GN_CHECK(need(G.WAh, true));
       GN_CHECK(need(G.bA, true));
       GN_CHECK(need(G.A, true));
       if (G.KA < 1 || G.KA > GN_MAX_TYPES) return GN_ERR_SHAPE;
@@ -902,7 +914,13 @@ extern "C" int gn_node_mlp_f32(const gn_node_group_t* groups, int n_groups, int 
   if (rows <= 0) return GN_ERR_SHAPE;
   const int xm = x_mode(groups, n_groups, [](const gn_node_group_t& G) { return G.Wx != nullptr; });
   if (xm < 0) return GN_ERR_SHAPE;
-  if (xm == 1) return node_stage_launch<3, float>(groups, n_groups, rows, (hipStream_t)stream);
+  if (xm == 1) {
+    // f16x3 (two fp16 parts, bf16x6 fallback inside the launch) when every group carries the fp16 image too
+    const int hm = x_mode(groups, n_groups, [](const gn_node_group_t& G) { return G.Wh != nullptr; });
+    if (hm < 0) return GN_ERR_SHAPE;
+    return hm ? node_stage_launch<2, float>(groups, n_groups, rows, (hipStream_t)stream)
+              : node_stage_launch<3, float>(groups, n_groups, rows, (hipStream_t)stream);
+  }
   GroupTable<gn_node_group_t> T{};
   T.n = n_groups;
   for (int g = 0; g < n_groups; ++g) {
@@ -968,7 +986,7 @@ static int edge_launch(const gn_edge_group_t* groups, int n_groups, float tau, u
   T.first_wg[n_groups] = wg;
   // LDS for the staged node rows of the fused pairwise pooling (the largest any group wants, at most 48 KiB; a group
   // that would need more pools straight from L2).  GN_POOL_STAGE = 0 switches the stage off.
-  static const bool no_pool_stage = getenv("GN_POOL_STAGE") != nullptr && atoi(getenv("GN_POOL_STAGE")) == 0;
+  const bool no_pool_stage = getenv("GN_POOL_STAGE") != nullptr && atoi(getenv("GN_POOL_STAGE")) == 0;   // (per call: tests toggle it)
   auto pool_bytes_for = [&](int wg_rows) {
     size_t need = 0;
     for (int g = 0; g < n_groups && !no_pool_stage; ++g) {
@@ -1003,9 +1021,15 @@ static int edge_launch(const gn_edge_group_t* groups, int n_groups, float tau, u
                        (int)pb);
   }
   else if (xm) {
+    const int hm = x_mode(groups, n_groups, [](const gn_edge_group_t& G) { return G.Wh != nullptr; });
+    if (hm < 0) return GN_ERR_SHAPE;
     const size_t pb = pool_bytes_for(128);
-    hipLaunchKernelGGL((edge_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), pb, stream, T, tau, seed, offset_dev,
-                       (int)pb);
+    if (hm)
+      hipLaunchKernelGGL((edge_x_kernel<2, float>), dim3(table_xcd_grid(T)), dim3(256), pb, stream, T, tau, seed, offset_dev,
+                         (int)pb);
+    else
+      hipLaunchKernelGGL((edge_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), pb, stream, T, tau, seed, offset_dev,
+                         (int)pb);
   }
   else
     hipLaunchKernelGGL(edge_mlp_gumbel_kernel, dim3(wg), dim3(256), 0, stream, T, tau, seed, offset_dev);
@@ -1065,13 +1089,13 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
     T.g[g].a = G;
     T.g[g].wpr = wpr;
     // pair form with one wave per row block: stage the scenes' node rows in LDS when they fit
-    static const bool no_stage = getenv("GN_AGG_NO_STAGE") != nullptr;
+    const bool no_stage = getenv("GN_AGG_NO_STAGE") != nullptr;
     T.g[g].stage = (!no_stage && G.A != nullptr && wpr == 1 &&
                     (127 / G.E + 2) * G.N <= (xm ? kStageMaxNodesX : kStageMaxNodes)) ? 1 : 0;
   }
   // Workgroups are dispatched in index order: give the low indices to the group whose waves run longest
   // (types x layers per wave), so the long waves start first and the short ones fill the tail.
-  static const bool as_given = getenv("GN_AGG_ORDER_AS_GIVEN") != nullptr;
+  const bool as_given = getenv("GN_AGG_ORDER_AS_GIVEN") != nullptr;
   if (!as_given) {
     auto cost = [](const AggGroup& a) { return (long long)a.a.K * (a.a.A != nullptr ? 1 : 2) * 4 / a.wpr; };
     for (int i = 1; i < n_groups; ++i)        // insertion sort, stable, n <= GN_MAX_GROUPS
@@ -1102,7 +1126,7 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
       }
       T.first_wg[n_groups] = wg;
       // LDS for the staged ori rows of the pairwise gather (GN_POOL_STAGE = 0 switches it off)
-      static const bool no_stage = getenv("GN_POOL_STAGE") != nullptr && atoi(getenv("GN_POOL_STAGE")) == 0;
+      const bool no_stage = getenv("GN_POOL_STAGE") != nullptr && atoi(getenv("GN_POOL_STAGE")) == 0;   // (per call)
       size_t sb = 0;
       for (int g = 0; g < n_groups && !no_stage; ++g) {
         const gn_agg_group_t& a = T.g[g].a;
@@ -1115,7 +1139,7 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
     }
   }
   // fused hyper gather in line layout (bf16-core kernels; GN_AGG_LINES = 0 keeps the per-lane gather): needs the LDS too
-  static const bool no_lines = getenv("GN_AGG_LINES") != nullptr && atoi(getenv("GN_AGG_LINES")) == 0;
+  const bool no_lines = getenv("GN_AGG_LINES") != nullptr && atoi(getenv("GN_AGG_LINES")) == 0;
   for (int g = 0; g < n_groups; ++g) {
     const gn_agg_group_t& a = T.g[g].a;
     T.g[g].lines = (xm && !no_lines && a.A == nullptr && a.eo == nullptr && a.H != nullptr && a.N <= 64) ? 1 : 0;
@@ -1125,9 +1149,16 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
   const size_t part_bytes = need_part ? kAggPartBytes : 0;
   if (twin)
     hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
-  else if (xm)
-    hipLaunchKernelGGL((agg_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
-  else
+  else if (xm) {
+    const int hm = x_mode(groups, n_groups, [](const gn_agg_group_t& G) {
+      return (G.A != nullptr ? G.W2h : G.W12h) != nullptr;
+    });
+    if (hm < 0) return GN_ERR_SHAPE;
+    if (hm)
+      hipLaunchKernelGGL((agg_x_kernel<2, float>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
+    else
+      hipLaunchKernelGGL((agg_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
+  } else
     hipLaunchKernelGGL(agg_mlp_kernel, dim3(wg), dim3(256), 0, stream, T);
   return gn_check_launch();
 }
@@ -1225,7 +1256,12 @@ static int mlp2_launch(const gn_mlp2_group_t* groups, int n_groups, int rows, in
     T.g[g] = G;
   }
   if (twin) return mlp2_x_launch<1, __bf16>(T, n_groups, rows, din, dh, dout, ldy, N, divisor, s);
-  if (xm) return mlp2_x_launch<3, float>(T, n_groups, rows, din, dh, dout, ldy, N, divisor, s);
+  if (xm) {
+    const int hm = x_mode(groups, n_groups, [](const gn_mlp2_group_t& G) { return G.Wh != nullptr; });
+    if (hm < 0) return GN_ERR_SHAPE;
+    return hm ? mlp2_x_launch<2, float>(T, n_groups, rows, din, dh, dout, ldy, N, divisor, s)
+              : mlp2_x_launch<3, float>(T, n_groups, rows, din, dh, dout, ldy, N, divisor, s);
+  }
   const dim3 block(256);
   const int blocks32 = (rows + 31) / 32;
   bool fused = false;   // (also set when activations are to be kept: only the whole-chain kernel writes them)

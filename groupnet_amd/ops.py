@@ -59,6 +59,25 @@ launch_probe = None
 
 
 BF16X6 = os.environ.get("GN_BF16X6", "1") != "0"   # fp32 entry points: fp32-accurate products on the bf16 cores
+# ... and, on top of it, the two-part fp16 path ("f16x3": three part-products per product instead of six, bf16x6 as the
+# in-kernel fallback for operands beyond the fp16 range).  GN_PRECISION = bf16x6 keeps the six-product path.
+F16X3 = BF16X6 and os.environ.get("GN_PRECISION", "f16x3").lower() != "bf16x6"
+
+
+def precision() -> str:
+    """Matrix path of the fp32 entry points: 'f16x3' (default), 'bf16x6' or 'fp32' (the fp32 matrix cores)."""
+    return "f16x3" if (BF16X6 and F16X3) else ("bf16x6" if BF16X6 else "fp32")
+
+
+def set_precision(mode: str) -> None:
+    """Select the matrix path of the fp32 entry points for launches issued from now on: 'f16x3' | 'bf16x6' | 'fp32'.
+    (Captured graphs keep the path they were captured with.)"""
+    global BF16X6, F16X3
+    mode = mode.lower()
+    if mode not in ("f16x3", "bf16x6", "fp32"):
+        raise ValueError("precision: 'f16x3', 'bf16x6' or 'fp32'")
+    BF16X6 = mode != "fp32"
+    F16X3 = mode == "f16x3"
 
 
 def _twin(dtype: torch.dtype) -> bool:
@@ -90,8 +109,11 @@ class XImages:
         hit = self.img.get((name, parts))
         src = self.src[name]
         if hit is None:
-            hit = self.img[(name, parts)] = [torch.empty(src.numel() // 1024 * 2 * parts * 64 * 8, dtype=torch.int16,
-                                                         device=src.device), -1]
+            n = src.numel() // 1024 * 2 * parts * 64 * 8
+            # (two fp16 parts: + the 16-byte flag word behind the image, zero-initialised once)
+            buf = (torch.zeros(n + 8, dtype=torch.int16, device=src.device) if parts == 2 else
+                   torch.empty(n, dtype=torch.int16, device=src.device))
+            hit = self.img[(name, parts)] = [buf, -1]
         if hit[1] != self.version:
             split_bf16(src, hit[0], parts)
             hit[1] = self.version
@@ -109,6 +131,14 @@ def _ximg(pk: dict, name: str, dtype: torch.dtype) -> int:
     if not BF16X6 or xi is None or name not in xi.src:
         return 0
     return xi.get(name, 3).data_ptr()
+
+
+def _himg(pk: dict, name: str, dtype: torch.dtype) -> int:
+    """Device address of the two-part fp16 image `name` (f16x3 path of the fp32 entry points), or 0."""
+    xi = pk.get("xi")
+    if _twin(dtype) or not (BF16X6 and F16X3) or xi is None or name not in xi.src:
+        return 0
+    return xi.get(name, 2).data_ptr()
 
 
 class _Probed:
@@ -513,6 +543,7 @@ def node_stage_grouped(items: Sequence[Tuple[Tensor, dict]], keep: Optional[List
         wx = _ximg(pk, "chain", dt)
         a_fields = (0, 0, 0, 0)
         A = None
+        wah = 0
         spec = a_specs[g] if a_specs is not None else None
         if spec is not None:
             if _twin(dt):
@@ -521,11 +552,12 @@ def node_stage_grouped(items: Sequence[Tuple[Tensor, dict]], keep: Optional[List
             if wx:
                 A = torch.empty(tuple(x.shape[:-1]) + (K * 128,), dtype=x.dtype, device=x.device)
                 a_fields = (_ximg(apk, "W1cat", dt), apk["b1half"].data_ptr(), A.data_ptr(), K)
+                wah = _himg(apk, "W1cat", dt)
             else:
                 late.append((g, x, apk, K))
         As.append(A)
         arr[g] = _lib.NodeGroup(x.data_ptr(), pk["W"].data_ptr(), pk["bias"].data_ptr(), xp.data_ptr(), pq.data_ptr(),
-                                hid_ptr, wx, *a_fields)
+                                hid_ptr, wx, *a_fields, _himg(pk, "chain", dt) if wx else 0, wah)
         outs.append((xp, pq))
     flops = sum(rows * 2 * (64 * 256 + 256 * 64 + 64 * 64 + (64 * 128 * int(a.KA) if a.A else 0)) for a in arr)
     with torch.cuda.device(x0.device), _Probed("node_stage_kernel", flops):
@@ -692,7 +724,7 @@ def edge_mlp_gumbel_grouped(items: Sequence[tuple], tau: float = 0.5, keep: Opti
             pool.b2.data_ptr(), pool.xp.shape[1], 0 if pool.H is None else pool.H.shape[1])
         arr[g] = _lib.EdgeGroup(0 if pool is not None else edges.data_ptr(), u_ptr, pk["W"].data_ptr(),
                                 pk["bias"].data_ptr(), edge_feat.data_ptr(), 0 if dist is None else dist.data_ptr(), off,
-                                B * E, K, sym_N, *kp, _ximg(pk, "edge", dt), *pool_args)
+                                B * E, K, sym_N, *kp, _ximg(pk, "edge", dt), *pool_args, _himg(pk, "edge", dt))
         outs.append((edge_feat, dist))
     flops = sum(int(a.rows) for a in arr) * 2 * (64 * 128 + 128 * 64 + 64 * 256 + 256 * 32)
     with torch.cuda.device(e0.device), _Probed("edge_mlp_gumbel_kernel", flops):
@@ -762,11 +794,14 @@ class PairSpec:
 
 def split_bf16(packed: Tensor, out: Optional[Tensor] = None, parts: int = 3) -> Tensor:
     """bf16-core image (16-bit words, as int16) of packed fp32 32x32 weight tiles: `gn_split_bf16_f32`
-    (parts = 3: x = p1 + p2 + p3, the fp32-accurate path; parts = 1: x rounded to bf16, the twins)."""
+    (parts = 3: x = p1 + p2 + p3, the fp32-accurate path; parts = 1: x rounded to bf16, the twins; parts = 2: two fp16
+    parts x = hi + lo — the f16x3 path — followed by the 16-byte range flag)."""
     _req(packed, "packed")
     n_tiles = packed.numel() // 1024
     if out is None:
-        out = torch.empty(n_tiles * 2 * parts * 64 * 8, dtype=torch.int16, device=packed.device)
+        n = n_tiles * 2 * parts * 64 * 8
+        out = (torch.zeros(n + 8, dtype=torch.int16, device=packed.device) if parts == 2 else     # (+ the flag word)
+               torch.empty(n, dtype=torch.int16, device=packed.device))
     if _REPACK["rec"] is not None:
         _REPACK["rec"][1].append((packed, out, int(parts)))
     elif _REPACK["done_splits"] is not None and (packed.data_ptr(), out.data_ptr(), int(parts)) in _REPACK["done_splits"]:
@@ -794,7 +829,7 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
             E = pair_count(N)
             _same_device(A, edge_feat)
             like, eo_ptr, wkey = A, 0, "W2t"
-            extra = (0, 0, E, N, 1, A.data_ptr(), _ximg(pk, "W2t", A.dtype), 0)
+            extra = (0, 0, E, N, 1, A.data_ptr(), _ximg(pk, "W2t", A.dtype), 0, _himg(pk, "W2t", A.dtype), 0)
         elif isinstance(eo, GatherSpec):
             ori, H = eo.ori, eo.H
             _req(ori, "ori", (None, None, FEAT), _ACT_DTYPES)
@@ -803,13 +838,13 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
             _same_device(ori, H, edge_feat)
             like, eo_ptr = ori, 0
             extra = (ori.data_ptr(), 0 if H is None else H.data_ptr(), E, N, int(eo.sym), 0, 0,
-                     _ximg(pk, "W12", ori.dtype))
+                     _ximg(pk, "W12", ori.dtype), 0, _himg(pk, "W12", ori.dtype))
         else:
             _req(eo, "eo", (None, None, FEAT), _ACT_DTYPES)
             B, E, _ = eo.shape
             _same_device(eo, edge_feat)
             like, eo_ptr = eo, eo.data_ptr()
-            extra = (0, 0, 0, 0, 0, 0, 0, _ximg(pk, "W12", eo.dtype))
+            extra = (0, 0, 0, 0, 0, 0, 0, _ximg(pk, "W12", eo.dtype), 0, _himg(pk, "W12", eo.dtype))
         dev0, dt = dev0 or like.device, dt or like.dtype
         if like.device != dev0 or like.dtype != dt:
             raise ValueError("grouped launch: every group must be on the same device and of the same storage type")
@@ -955,7 +990,7 @@ def mlp2_grouped(items: Sequence[Tuple[object, dict, Optional[Tensor]]], keep: O
             keep.append(kd)
             kp = (kd["x"].data_ptr(), kd["hid"].data_ptr())
         arr[g] = _lib.Mlp2Group(fields[0], fields[1], fields[2], y.data_ptr(), *fields[4:], *kp,
-                                _ximg(pk, "mlp2", dt) if dout <= 64 else 0)
+                                _ximg(pk, "mlp2", dt) if dout <= 64 else 0, _himg(pk, "mlp2", dt) if dout <= 64 else 0)
         outs.append(y)
     rows = 1
     for d_ in shape0:

@@ -29,6 +29,20 @@
  *     part-products per product on the bf16 matrix cores — as accurate as fp32 accumulation, faster than the
  *     fp32 matrix cores; without it the launch falls back to v_mfma_f32_32x32x2_f32 on the plain packed stream.
  *     Either all groups of a launch carry it or none.
+ *   - `Wh` images (`Wh`, `WAh`, `W2h`, `W12h`; ABI 30): the SAME tile stream split into TWO fp16 parts per weight
+ *     (gn_split_bf16_f32 with parts = 2) — the "f16x3" path: three v_mfma_f32_32x32x16_f16 part-products per product,
+ *     fp32-accurate (3e-7 of max|result| at K = 256), about twice the rate of the six-product bf16 path.  fp16 has a
+ *     narrow exponent, so a group that carries `Wh` MUST also carry the corresponding `Wx` image: a workgroup that
+ *     meets an operand beyond 65000 in magnitude (or a flagged weight image) repeats its rows on the bf16 path inside
+ *     the same launch.  Either all groups of a launch carry `Wh` or none.  The image is followed by a 16-byte FLAG
+ *     word the caller zero-initialises once (the split raises it when a weight does not fit fp16).
+ *   - Order of the tiles in every bf16-/fp16-core image of a LAYER PAIR  out += W1 act(W0 x)  ("pipeline order", the
+ *     order the kernels consume them; ops.pipeline_order): with A_t = the first-layer tiles [W0(t, in 0..IT-1)] that
+ *     produce hidden tile t and B_t = the second-layer tiles [W1(0..OT-1, t)] that consume it:
+ *         A0 A1 B0 A2 B1 ... A(HT-1) B(HT-2) B(HT-1)
+ *     (NOT hidden-tile-major [A_t B_t]: A_{t+1} is issued between A_t and B_t so that the splitting of hidden tile t
+ *     runs in the shadow of the matrix pipe).  Sub-step offset of A_t: t == 0 ? 0 : NA + (t-1)(NA+NB); of B_t:
+ *     t < HT-1 ? 2 NA + t (NA+NB) : HT NA + (HT-1) NB, with NA = 2 IT, NB = 2 OT sub-steps (two per 32x32 tile).
  */
 #ifndef GROUPNET_HIP_H
 #define GROUPNET_HIP_H
@@ -169,9 +183,10 @@ typedef struct {
   float* xp;        /* [T] */
   float* pq;        /* [T] */
   float* hid_out;   /* optional (training): the hidden activations relu(W0 x + b0) (rows, 256) */
-  const void* Wx;   /* optional bf16-core image of the chain, hidden-tile-major (72 sub-steps): per hidden tile t
-                       of W0 the tiles [W0(t,in0), W0(t,in1), W1(0,t), W1(1,t)], then [Wpq(0,in0), Wpq(0,in1),
-                       Wpq(1,in0), Wpq(1,in1)].  With it W may be NULL. */
+  const void* Wx;   /* optional bf16-core image of the chain (72 sub-steps): the layer pair W0 (256x64) / W1 (64x256)
+                       in PIPELINE order (header comment: A_t = [W0(t,in0), W0(t,in1)], B_t = [W1(0,t), W1(1,t)],
+                       A0 A1 B0 A2 B1 ... A7 B6 B7), then [Wpq(0,in0), Wpq(0,in1), Wpq(1,in0), Wpq(1,in1)].
+                       With it W may be NULL. */
   /* optional, with Wx only: the per-node first layer of the typed aggregation MLP of the pairwise graph in the
    * SAME launch (it reads the same node rows; see gn_node_linear_f32): A = WA x + bA, A (rows, KA*128) [T],
    * WAx = bf16-core image of the packed (KA*128 x 64) matrix, bA (KA*128) fp32.  A == NULL: not computed. */
@@ -179,6 +194,8 @@ typedef struct {
   const float* bA;
   float* A;         /* [T] */
   int KA;
+  const void* Wh;   /* optional fp16 two-part image of the same chain stream as Wx (f16x3 path; needs Wx too) */
+  const void* WAh;  /* ... of the same stream as WAx (required with Wh when A != NULL) */
 } gn_node_group_t;
 int gn_node_mlp_f32(const gn_node_group_t* groups, int n_groups, int rows, gn_stream_t stream);
 int gn_node_mlp_bf16(const gn_node_group_t* groups, int n_groups, int rows, gn_stream_t stream);
@@ -246,10 +263,10 @@ typedef struct {
   float* keep_z;
   float* keep_dh1;
   float* keep_lgf;
-  const void* Wx;    /* optional bf16-core image (gn_split_bf16_f32) of the hidden-tile-major fp32 stream of the four
-                        layers — per hidden tile t of init_MLP: [Wi0(t,in0), Wi0(t,in1), Wi1(0,t), Wi1(1,t)], then
-                        per hidden tile t of [Wd0]: [Wd0(t,in0), Wd0(t,in1), Wd1(0,t)] — 40 tiles = 80 sub-steps.
-                        With it W may be NULL. */
+  const void* Wx;    /* optional bf16-core image (gn_split_bf16_f32) of the fp32 tile stream of the four layers, two
+                        layer pairs in PIPELINE order (header comment) — pair A (init_MLP, 4 hidden tiles): A_t =
+                        [Wi0(t,in0), Wi0(t,in1)], B_t = [Wi1(0,t), Wi1(1,t)]; pair B (8 hidden tiles): A_t =
+                        [Wd0(t,in0), Wd0(t,in1)], B_t = [Wd1(0,t)] — 40 tiles = 80 sub-steps.  With it W may be NULL. */
   /* Fused node->edge pooling (bf16-core kernels only, i.e. with Wx): edges == NULL and xp != NULL — every row of
    * `edges` is formed inside the kernel exactly as gn_node2edge_* would have written it (MS_HGNN_batch.py:127-141,
    * 359-370) and never touches HBM.  xp / pq: (B*N, 64) outputs of gn_node_mlp_*; w2 (32), b2 (1): attention layer 1;
@@ -262,6 +279,7 @@ typedef struct {
   const float* b2;
   int pool_N;
   int pool_E;
+  const void* Wh;    /* optional fp16 two-part image of the same stream as Wx (f16x3 path; needs Wx too) */
 } gn_edge_group_t;
 int gn_edge_mlp_gumbel_f32(const gn_edge_group_t* groups, int n_groups, float tau, unsigned long long seed,
                            const unsigned long long* offset_dev, gn_stream_t stream);
@@ -309,10 +327,13 @@ typedef struct {
   int sym;
   const float* A;
   const void* W2x;    /* optional, pair form (fp32 entry point only): bf16-core image of layer 2 of every type
-                         (gn_split_bf16_f32 of the hidden-tile-major W image, 16 sub-steps per type) */
-  const void* W12x;   /* optional, two-layer form: bf16-core image of both layers, hidden-tile-major: per type and
-                         hidden tile o the tiles [W1k(o, in 0), W1k(o, in 1), W2k(out 0, o), W2k(out 1, o)]
-                         (32 sub-steps per type).  With W2x / W12x, W may be NULL. */
+                         (gn_split_bf16_f32 of the hidden-tile-major W image: per type and hidden tile t the tiles
+                         [W2k(0,t), W2k(1,t)], 16 sub-steps per type) */
+  const void* W12x;   /* optional, two-layer form: bf16-core image of both layers, per type one layer pair in PIPELINE
+                         order (header comment): A_t = [W1k(t, in 0), W1k(t, in 1)], B_t = [W2k(out 0, t), W2k(out 1, t)],
+                         A0 A1 B0 A2 B1 A3 B2 B3 (32 sub-steps per type).  With W2x / W12x, W may be NULL. */
+  const void* W2h;    /* optional fp16 two-part images of the same streams as W2x / W12x (f16x3 path; need those too) */
+  const void* W12h;
 } gn_agg_group_t;
 int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream);
 /* twin: two-layer form only (eo, or the fused gather from ori) — a per-node first layer stored in bf16 would
@@ -323,7 +344,9 @@ int gn_agg_mlp_bf16(const gn_agg_group_t* groups, int n_groups, gn_stream_t stre
  * v_mfma_f32_32x32x16_bf16: out[(((tile*2 + half)*parts + part)*64 + lane)*8 + j] (16-bit words), where
  * element j of lane (m, h) is the weight of output m and k-feature 16*half + (j&3) + 8*(j>>2) + 4*h — the
  * order in which a lane's accumulator registers hold those features.  parts = 3: x = p1 + p2 + p3 (8 mantissa
- * bits each, round to nearest: the fp32-accurate path); parts = 1: p1 = x rounded to bf16 (the bf16 twins). */
+ * bits each, round to nearest: the fp32-accurate path); parts = 1: p1 = x rounded to bf16 (the bf16 twins);
+ * parts = 2: TWO fp16 parts x = hi + lo (the `Wh` images of the f16x3 path) — `out` then holds 16 more bytes behind
+ * the image, the FLAG word (zero-initialised by the caller once), which the split raises when |x| > 65000. */
 int gn_split_bf16_f32(const float* packed, void* out, int n_tiles, int parts, gn_stream_t stream);
 /* The same for `n_jobs` images in ONE launch (job table in DEVICE memory; max_tiles = the largest n_tiles): what a
  * training step needs after its optimizer update — every weight image of every module, one launch after the one
@@ -389,9 +412,10 @@ typedef struct {
   float* in_out;    /* optional (training): the MLP's input rows as evaluated (rows, din) — with the fused
                        scatter that is cat(H^T feat, ori)/N, which otherwise never exists in memory */
   float* hid_out;   /* optional (training): the hidden activations relu(W0 x + b0) (rows, dh) */
-  const void* Wx;   /* optional bf16-core image, hidden-tile-major: per hidden tile t the tiles
-                       [W0(t, in 0..din/32-1), W1(0..ceil(dout/32)-1, t)]; used when dout <= 64 (else the launch
-                       needs W).  With it W may be NULL. */
+  const void* Wx;   /* optional bf16-core image, one layer pair in PIPELINE order (header comment): A_t =
+                       [W0(t, in 0..din/32-1)], B_t = [W1(0..ceil(dout/32)-1, t)]; used when dout <= 64 (else the
+                       launch needs W).  With it W may be NULL. */
+  const void* Wh;   /* optional fp16 two-part image of the same stream (f16x3 path; needs Wx too) */
 } gn_mlp2_group_t;
 int gn_mlp2_f32(const gn_mlp2_group_t* groups, int n_groups, int rows, int din, int dh, int dout, int ldy,
                 int N, float divisor, gn_stream_t stream);
