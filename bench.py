@@ -52,7 +52,8 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 matrix peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 matrix peak (same guide)
-X6_CEILING_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0   # fp32-accurate products = six bf16 part-products each
+X6_CEILING_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0   # bf16x6: fp32-accurate products = six bf16 part-products each
+X3_CEILING_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 3.0   # f16x3: three fp16 part-products each (fp16 MFMA rate = bf16 rate)
 
 
 def agg_hbm_bytes(B, N, E):
@@ -186,36 +187,224 @@ def cpu_share():
     return max(1, min(visible, quota)), visible
 
 
-def cpu_baseline(block_state, cfg, budget_s=20.0):
+def cpu_baseline(block_state, cfg, budget_s=24.0):
     """The oracle on the host cores: the same workload (pairwise + one hyper module per scale, host noise drawn as
-    the reference does, materialised attention tensor as the reference executes), on this job's share of the host
-    cores (`cpu_share`).  Bounded sample: as many forwards of `Bs` scenes as fit in ~budget_s (>= 2); Bs = the configuration's batch
-    when one forward takes well under the budget, else a slice of it (scenes are independent: scenes/s carries over)."""
+    the reference does) on this job's share of the host cores (`cpu_share`).  SURVEY 8d: B = 32 / 512 / 4096 at N = 11
+    (the configuration's own batch otherwise), the faithful form (materialised attention tensor, as the reference
+    executes) and the decomposed form, median / min / max of the forwards that fit a bounded budget (>= 2 after one
+    warm-up each).  `value` = the faithful form at the configuration's batch (scenes are independent: a slice of a
+    large-N batch carries over)."""
     from oracle import ms_hgnn_oracle as O
     cores, visible = cpu_share()
     torch.set_num_threads(cores)
     sp, shs = block_state
     N, scales, B = cfg["N"], cfg["scales"], cfg["B"]
     # the (Bs, N*N, N, 128) attention input of the reference costs Bs*N^3*512 bytes (x3 live copies)
-    Bs = B if N <= 16 else max(1, min(B, int(1.5e9 // (N ** 3 * 512 * 3))))
-    g = torch.Generator().manual_seed(1234)
-    h = torch.randn(Bs, N, 64, generator=g)
-    times = []
-    with torch.no_grad():
-        t_end = time.time() + budget_s
-        it = 0
-        while it < 2 or (time.time() < t_end and it < 12):
-            t0 = time.perf_counter()
-            Up = [O.draw_uniform(s) for s in O.noise_shapes(Bs, N, None)]
-            Uh = [[O.draw_uniform(s) for s in O.noise_shapes(Bs, N, sc)] for sc in scales]
-            O.ms_hgnn_multiscale_forward(sp, shs, scales, h, Up, Uh, decomposed=False)
-            times.append(time.perf_counter() - t0)
-            it += 1
-    best = statistics.median(times[1:]) if len(times) > 1 else times[0]
-    return dict(value=Bs / best, unit="scenes/s", cores=cores, cores_visible=visible, cpu_model=cpu_model(), kind="port",
-                sample=f"{len(times)} forwards of {Bs} scenes at N={N}, scales {scales} (median of all but the first); "
-                       f"torch {torch.__version__} CPU fp32 on {cores} threads, materialised attention tensor as the "
-                       f"reference executes")
+    cap = B if N <= 16 else max(1, min(B, int(1.5e9 // (N ** 3 * 512 * 3))))
+    sizes = sorted({32, B, 4096}) if N <= 16 else [cap]
+
+    def run(Bs, decomposed, budget, max_it):
+        g = torch.Generator().manual_seed(1234)
+        h = torch.randn(Bs, N, 64, generator=g)
+        times = []
+        with torch.no_grad():
+            t_end = time.time() + budget
+            while len(times) < 3 or (time.time() < t_end and len(times) < max_it):
+                t0 = time.perf_counter()
+                Up = [O.draw_uniform(s) for s in O.noise_shapes(Bs, N, None)]
+                Uh = [[O.draw_uniform(s) for s in O.noise_shapes(Bs, N, sc)] for sc in scales]
+                O.ms_hgnn_multiscale_forward(sp, shs, scales, h, Up, Uh, decomposed=decomposed)
+                times.append(time.perf_counter() - t0)
+                if len(times) >= 3 and time.time() >= t_end:
+                    break
+        t = times[1:]                      # (the first forward warms the allocator / thread pool)
+        return dict(scenes=Bs, forwards=len(t), scenes_per_s=round(Bs / statistics.median(t), 1),
+                    min=round(Bs / max(t), 1), max=round(Bs / min(t), 1))
+
+    per = budget_s / (2.0 * len(sizes))
+    table = {}
+    for Bs in sizes:
+        table[f"B{Bs}"] = dict(faithful=run(Bs, False, per, 10), decomposed=run(Bs, True, per, 10))
+    main = table[f"B{min(B, cap)}"]["faithful"]
+    return dict(value=main["scenes_per_s"], unit="scenes/s", min=main["min"], max=main["max"], cores=cores,
+                cores_visible=visible, cpu_model=cpu_model(), kind="port", by_batch=table,
+                sample=f"{main['forwards']} forwards of {main['scenes']} scenes at N={N}, scales {scales} (median, min, max "
+                       f"of all but the first); torch {torch.__version__} CPU fp32 on {cores} threads, materialised "
+                       f"attention tensor as the reference executes; by_batch: the same at the other batch sizes and "
+                       f"the decomposed-attention variant")
+
+
+def matrix_path(twin):
+    """(description, peak TFLOP/s, name) of the matrix path the fp32 / bf16 entry points run on, for the roofline: the
+    peak is the dense 16-bit MFMA peak divided by the part-products ONE product of the path costs."""
+    from groupnet_amd import ops
+    if twin:
+        return ("v_mfma_f32_32x32x16_bf16, bf16 operands, fp32 accumulate", MFMA_BF16_PEAK_TFLOPS, "bf16")
+    mode = ops.precision()
+    if mode == "f16x3":
+        return ("v_mfma_f32_32x32x16_f16, x = xh + xl (two fp16 parts), three part-products per product (fp32-accurate; "
+                "operands beyond the fp16 range fall back to bf16x6 inside the launch)", X3_CEILING_TFLOPS, "f16x3")
+    if mode == "bf16x6":
+        return ("v_mfma_f32_32x32x16_bf16, x = x1+x2+x3 (bf16 parts), six part-products per product (fp32-accurate)",
+                X6_CEILING_TFLOPS, "bf16x6")
+    return ("v_mfma_f32_32x32x2_f32", MFMA_F32_PEAK_TFLOPS, "fp32")
+
+
+def roofline_leg(block, f, cfg_name, twin, N, n_steps):
+    """Brackets every launch of the matrix-core kernels of `n_steps` eager single-stream forwards with HIP events on the
+    stream they are launched on.  Returns (roofline of the kernel with the largest launch time, all kernels).
+    `achieved` = algorithmic fp32-equivalent FLOPs per launch / average launch duration; `peak` = what the matrix path
+    can issue at best: 2.5 PF dense 16-bit MFMA / part-products per product (3 for f16x3, 6 for bf16x6, 1 for the
+    twins); the fraction of the fp32 matrix peak (157.3 TF, the metric's precision) is reported next to it."""
+    import groupnet_amd as G
+    from groupnet_amd import ops
+    G.set_noise_mode("device", seed=99)
+    probe = Probe()
+    for _ in range(2):
+        block(f)
+    ops.launch_probe = probe
+    torch.cuda.synchronize()
+    for _ in range(n_steps):
+        torch.cuda._sleep(3_000_000 if N <= 16 else 12_000_000)   # keep the host ahead: no launch gaps in the brackets
+        block(f)
+    ops.launch_probe = None
+    torch.cuda.synchronize()
+    overhead = empty_bracket_ms()
+    summ = probe.summary(overhead)
+    desc, peak, pname = matrix_path(twin)
+    parts = {"f16x3": 3, "bf16x6": 6}.get(pname, 1)
+    kernels = {}
+    for k, (ms, fl, n) in summ.items():
+        tf = fl / (ms * 1e-3) / 1e12
+        kernels[k] = dict(avg_launch_us=round(ms * 1e3, 2), flops_per_launch=fl, achieved_tflops=round(tf, 2),
+                          frac=round(tf / peak, 4), frac_of_fp32_matrix_peak=round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                          executed_16bit_tflops=round(parts * tf, 1))
+    dom = max(summ, key=lambda k: summ[k][0])       # the kernel with the largest launch time
+    ms, fl, nl = summ[dom]
+    ach = fl / (ms * 1e-3) / 1e12
+    # (the stage's device kernel: large bf16 launches run the two-row-blocks-per-wave kernels)
+    traffic, tfile = pmc_traffic([{"agg_mlp_kernel": ("agg_x_kernel", "agg_rb2_kernel"),
+                                   "edge_mlp_gumbel_kernel": ("edge_x_kernel", "edge_rb2_kernel"),
+                                   "node_stage_kernel": "node_stage_kernel", "mlp2_kernel": "mlp2_x_kernel"}.get(dom, dom)],
+                                 cfg_name)
+    roof = dict(kernel=dom + {"agg_mlp_kernel": " (typed aggregation MLP, all modules in one grouped launch)",
+                              "edge_mlp_gumbel_kernel": " (edge MLP 64-128-64 + distribution/factor heads + Gumbel "
+                                                        "softmax epilogue, all modules in one grouped launch)",
+                              "node_stage_kernel": " (node MLP 64-256-64 + attention projections + per-node typed "
+                                                   "layer 1, all modules in one grouped launch)"}.get(dom, ""),
+                bound="mfma", achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
+                frac=round(ach / peak, 4), traffic=traffic, traffic_source=tfile,
+                avg_launch_us=round(ms * 1e3, 2), flops_per_launch=fl, launches_timed=nl,
+                event_pair_overhead_us=round(overhead * 1e3, 2), matrix_path=desc,
+                peak_is=f"{MFMA_BF16_PEAK_TFLOPS:.0f} TFLOP/s dense 16-bit MFMA / {parts} part-product(s) per product",
+                frac_of_fp32_matrix_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                executed_16bit_tflops=round(parts * ach, 1),
+                measured="single-stream instrumented eager pass (in the timed region steps overlap across streams, "
+                         "which stretches every kernel; profiles/ holds both views)")
+    return roof, kernels
+
+
+def agg_hbm_leg(dev, Bb=4096, Nn=11, sets=16):
+    """north_star: the hyperedge aggregation gather + scatter kernels against the HBM roofline at N=11 / B=4096 (fp32).
+    Two figures: `frac` = the launch pair repeated on ONE set of buffers (60 MB: resident in the 256 MiB Infinity Cache
+    after the first pass — an on-die figure) and `frac_cold` = the same launches rotating over `sets` distinct buffer
+    sets (~1 GB footprint, 4x the Infinity Cache: every launch streams from HBM).  `frac_cold` is the HBM figure."""
+    from groupnet_amd import ops
+    by = agg_hbm_bytes(Bb, Nn, Nn)
+    bufs = []
+    for i in range(sets):
+        ori = torch.randn(Bb, Nn, 64, device=dev)
+        _, Hs, _ = ops.affinity_topk(ori, [5], want_corr=False)
+        bufs.append((ori, Hs[0], torch.randn(Bb, Nn, 64, device=dev)))
+    ori, H, feat = bufs[0]
+    t_g = time_kernel_ms(lambda: ops.agg_gather(ori, H))
+    t_s = time_kernel_ms(lambda: ops.agg_scatter(feat, H, ori))
+    gbs = by / ((t_g + t_s) * 1e-3) / 1e9
+    it = [0]
+
+    def rot(fn):
+        def go():
+            o, h, ft = bufs[it[0] % sets]
+            it[0] += 1
+            fn(o, h, ft)
+        return go
+    tc_g = time_kernel_ms(rot(lambda o, h, ft: ops.agg_gather(o, h)), reps=4 * sets, warm=sets)
+    tc_s = time_kernel_ms(rot(lambda o, h, ft: ops.agg_scatter(ft, h, o)), reps=4 * sets, warm=sets)
+    gbs_c = by / ((tc_g + tc_s) * 1e-3) / 1e9
+    footprint = sets * (3 * Bb * Nn * 64 * 4 + Bb * Nn * Nn * 4 + Bb * Nn * 64 * 4 + Bb * Nn * 128 * 4)   # + outputs
+    atr, afile = pmc_traffic(["agg_gather_kernel", "agg_scatter_kernel"], "c2")
+    return dict(kernel="agg_gather_kernel + agg_scatter_kernel (hyper, E=N=11, B=4096, fp32)", bound="hbm",
+                achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                achieved_cold=round(gbs_c, 1), frac_cold=round(gbs_c / HBM_PEAK_GBS, 4),
+                cold_is=f"{sets} rotating buffer sets, ~{footprint / 2**20:.0f} MiB touched between two uses of a line "
+                        f"(Infinity Cache: 256 MiB)",
+                traffic=atr, traffic_source=afile,
+                gather_us=round(t_g * 1e3, 2), scatter_us=round(t_s * 1e3, 2),
+                gather_us_cold=round(tc_g * 1e3, 2), scatter_us_cold=round(tc_s * 1e3, 2), bytes_per_launch_pair=by)
+
+
+def parity_mode_leg(block, f, B, N, steps=30):
+    """SURVEY 8d "parity mode": the reference's noise contract — every module call draws torch.rand((B,E,K)) from the
+    global CPU generator and the uniforms are uploaded (MS_HGNN_batch.py:454) — eager, one stream.  A side figure: the
+    step is bound by the host draw + four H2D copies, not by the GPU."""
+    import groupnet_amd as G
+    G.set_noise_mode("host")
+    for _ in range(3):
+        block(f)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        block(f)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return dict(what="eager forward with host noise: torch.rand on the CPU generator per module call + upload (the "
+                     "reference's RNG contract; outputs match the reference's for the same seed)",
+                scenes_per_s=round(B * steps / el, 1), ms_per_step=round(el / steps * 1e3, 3), steps=steps)
+
+
+def per_module_leg(block, f):
+    """Device time of each module of the block ALONE (eager launches bracketed by events, device noise): the pairwise
+    module and one hyper module per scale — each includes its own node / edge / aggregation / closing launches; the hyper
+    figures include the affinity + top-k launch that builds their incidence."""
+    import groupnet_amd as G
+    from groupnet_amd import ops
+    G.set_noise_mode("device", seed=7)
+    out = {}
+    t = time_kernel_ms(lambda: block.interaction(f), reps=20, warm=3)
+    out["pairwise"] = round(t * 1e3, 1)
+    for s, m in zip(block.hyper_scales, block.interaction_hyper):
+        def go(m=m, s=s):
+            corr, Hs, _ = ops.affinity_topk(f, [s], want_corr=True)
+            m(f, corr, H=Hs[0])
+        out[f"hyper_scale_{s}"] = round(time_kernel_ms(go, reps=20, warm=3) * 1e3, 1)
+    out["unit"] = "us per forward of the module alone (the grouped block launches all of them together)"
+    return out
+
+
+def c4_leg(dev, steps=40):
+    """BASELINE config 4 (N=50, B=1024, scales {2,4,8,16}, bf16 twins) as a short leg of the default run, so that its
+    number is observed by the driver: hipGraph replay on one stream, scenes/s, and the dominant kernel against the bf16
+    MFMA peak (the instrumented pass of `roofline_leg`)."""
+    from groupnet_amd.graphs import GraphedMultiScale
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    cfg = CONFIGS["c4"]
+    torch.manual_seed(0)
+    blk = MultiScaleHGNN(cfg["scales"]).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(1234)
+    f4 = torch.randn(cfg["B"], cfg["N"], 64, generator=g, device=dev).to(torch.bfloat16)
+    gr = GraphedMultiScale(blk, cfg["B"], cfg["N"], seed=5, dtype=torch.bfloat16)
+    gr.f_in.copy_(f4)
+    for _ in range(5):
+        gr()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gr()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    roof, kernels = roofline_leg(blk, f4, "c4", True, cfg["N"], 10)
+    return dict(workload=cfg["metric"], scenes_per_s=round(cfg["B"] * steps / el, 1), ms_per_step=round(el / steps * 1e3, 4),
+                steps=steps, streams=1, dtype="bf16", roofline=roof, mfma_kernels=kernels)
 
 
 def self_launch(n_gpus, port, dry):
@@ -250,6 +439,7 @@ def main():
                     help="consecutive steps are issued round-robin on this many HIP streams (each with its own "
                          "captured graph and output buffers), so the tail of one step overlaps the head of the next")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the training-step side measurement")
+    ap.add_argument("--no-c4-leg", action="store_true", help="skip the short BASELINE-config-4 side leg of the default run")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the multi-GPU code path (process group, bucketed all-gather) with one rank")
     ap.add_argument("--master-port", type=int, default=29533, help="rendezvous port of the self-launched N > 1 run")
@@ -356,78 +546,13 @@ def main():
             single = statistics.median(timer.measure(args.steps, step1, n_regions))
 
         # ---- roofline leg: instrumented eager pass (rank 0) ---------------------------------------------
-        roof = agg = mfma_kernels = train = None
+        roof = agg = mfma_kernels = train = parity = modules = c4 = None
         if rank == 0:
-            G.set_noise_mode("device", seed=99)
-            probe = Probe()
-            for _ in range(2):
-                block(f)
-            ops.launch_probe = probe
-            torch.cuda.synchronize()
-            for _ in range(min(args.steps, 50)):
-                torch.cuda._sleep(3_000_000 if N <= 16 else 12_000_000)   # keep the host ahead: no launch gaps in the brackets
-                block(f)
-            ops.launch_probe = None
-            torch.cuda.synchronize()
-            overhead = empty_bracket_ms()
-            summ = probe.summary(overhead)
-            peak = MFMA_BF16_PEAK_TFLOPS if twin else MFMA_F32_PEAK_TFLOPS
-            on_x6 = ops.BF16X6 and not twin
-            mfma_kernels = {}
-            for k, (ms, fl, n) in summ.items():
-                tf = fl / (ms * 1e-3) / 1e12
-                mk = dict(avg_launch_us=round(ms * 1e3, 2), flops_per_launch=fl, achieved_tflops=round(tf, 2),
-                          frac=round(tf / peak, 4))
-                if on_x6:
-                    # fp32-accurate products from six bf16 part-products on the bf16 cores: `frac` is the algorithmic
-                    # (fp32) work against the fp32 matrix peak; the ceiling of what the kernel ISSUES is 2.5 PF / 6
-                    mk["frac_of_issue_ceiling"] = round(tf / X6_CEILING_TFLOPS, 4)
-                    mk["executed_bf16_tflops"] = round(6 * tf, 1)
-                mfma_kernels[k] = mk
-            dom = max(summ, key=lambda k: summ[k][0])       # the kernel with the largest launch time
-            ms, fl, nl = summ[dom]
-            ach = fl / (ms * 1e-3) / 1e12
-            # (the stage's device kernel: large bf16 launches run the two-row-blocks-per-wave kernels)
-            traffic, tfile = pmc_traffic([{"agg_mlp_kernel": ("agg_x_kernel", "agg_rb2_kernel"),
-                                           "edge_mlp_gumbel_kernel": ("edge_x_kernel", "edge_rb2_kernel"),
-                                           "node_stage_kernel": "node_stage_kernel", "mlp2_kernel": "mlp2_x_kernel"}.get(dom, dom)],
-                                         args.config)
-            roof = dict(kernel=dom + {"agg_mlp_kernel": " (typed aggregation MLP, all modules in one grouped launch)",
-                                      "edge_mlp_gumbel_kernel": " (edge MLP 64-128-64 + distribution/factor heads + Gumbel "
-                                                                "softmax epilogue, all modules in one grouped launch)",
-                                      "node_stage_kernel": " (node MLP 64-256-64 + attention projections + per-node typed "
-                                                           "layer 1, all modules in one grouped launch)"}.get(dom, ""),
-                        bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
-                        frac=round(ach / peak, 4), traffic=traffic, traffic_source=tfile,
-                        avg_launch_us=round(ms * 1e3, 2), flops_per_launch=fl, launches_timed=nl,
-                        event_pair_overhead_us=round(overhead * 1e3, 2),
-                        matrix_path=("v_mfma_f32_32x32x16_bf16, bf16 operands, fp32 accumulate" if twin else
-                                     "v_mfma_f32_32x32x16_bf16, x = x1+x2+x3 (bf16 parts), six part-products per product "
-                                     "(fp32-accurate)" if on_x6 else "v_mfma_f32_32x32x2_f32"),
-                        measured="single-stream instrumented eager pass (in the timed region steps overlap across streams, "
-                                 "which stretches every kernel; profiles/ holds both views)")
-            if on_x6:
-                roof.update(note="algorithmic fp32 FLOPs against the fp32 matrix peak; the kernel executes six bf16 "
-                                 "part-products per product, so the ceiling of what it issues is 2.5 PF / 6 = 417 TFLOP/s "
-                                 "(frac_of_issue_ceiling)",
-                            frac_of_issue_ceiling=round(ach / X6_CEILING_TFLOPS, 4),
-                            executed_bf16_tflops=round(6 * ach, 1),
-                            frac_of_bf16_peak=round(6 * ach / MFMA_BF16_PEAK_TFLOPS, 4))
-            # ---- north_star: hyperedge aggregation gather+scatter vs HBM at N=11 / B=4096 (fp32) -------------
-            Bb, Nn = 4096, 11
-            ori = torch.randn(Bb, Nn, 64, device=dev)
-            _, Hs, _ = ops.affinity_topk(ori, [5], want_corr=False)
-            H = Hs[0]
-            feat = torch.randn(Bb, Nn, 64, device=dev)
-            t_g = time_kernel_ms(lambda: ops.agg_gather(ori, H))
-            t_s = time_kernel_ms(lambda: ops.agg_scatter(feat, H, ori))
-            by = agg_hbm_bytes(Bb, Nn, Nn)
-            gbs = by / ((t_g + t_s) * 1e-3) / 1e9
-            atr, afile = pmc_traffic(["agg_gather_kernel", "agg_scatter_kernel"], "c2")
-            agg = dict(kernel="agg_gather_kernel + agg_scatter_kernel (hyper, E=N=11, B=4096, fp32)", bound="hbm",
-                       achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
-                       traffic=atr, traffic_source=afile,
-                       gather_us=round(t_g * 1e3, 2), scatter_us=round(t_s * 1e3, 2), bytes_per_launch_pair=by)
+            roof, mfma_kernels = roofline_leg(block, f, args.config, twin, N, min(args.steps, 50))
+            agg = agg_hbm_leg(dev)
+            if world == 1:
+                parity = parity_mode_leg(block, f, Bl, N)
+                modules = per_module_leg(block, f)
             G.set_noise_mode("host")
             # ---- one training step (fwd + loss + bwd + SGD) replayed from one hipGraph ------
             try:
@@ -435,6 +560,12 @@ def main():
                          if (world == 1 and not args.no_train_leg and not twin) else None)
             except Exception as e:      # the headline forward numbers stand on their own
                 train = dict(error=f"{type(e).__name__}: {e}")
+            # ---- BASELINE config 4 beside the metric's configuration (a short leg: driver-observed, not the headline) ----
+            if world == 1 and args.config == "c2" and not args.no_c4_leg:
+                try:
+                    c4 = c4_leg(dev)
+                except Exception as e:
+                    c4 = dict(error=f"{type(e).__name__}: {e}")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -457,14 +588,15 @@ def main():
             "config": {"workload": f"MS-HGNN forward ({args.config}): affinity + top-k + pairwise + hyper scales {SCALES}, "
                                    f"N={N} agents, {Bl} scenes per GPU (global batch {B_total}), "
                                    + ("bf16 storage / fp32 accumulate (the *_bf16 twins of every stage), " if twin else
-                                      "fp32 in and out (matrix stages: fp32-accurate three-part bf16 products on the bf16 "
-                                      "matrix cores), " if ops.BF16X6 else "fp32 in and out (fp32 matrix cores), ")
+                                      f"fp32 in and out (matrix stages: {matrix_path(False)[2]} — {matrix_path(False)[0]}), ")
                                    + f"device Philox noise, {'eager' if args.no_graph else f'hipGraph replay on {S} alternating streams'}"
                                    + (f", + RCCL all-gather of the (B,N,{block.out_features}) embeddings, one call per {S} "
                                       f"steps, overlapped on a side stream" if distributed else ""),
                        "global_batch": B_total, "agents": N, "scales": SCALES,
                        "parallelism": f"batch-sharded x{world}"},
             "roofline": roof, "agg_hbm": agg, "mfma_kernels": mfma_kernels, "train_step": train,
+            "value_parity_mode": None if parity is None else parity["scenes_per_s"], "parity_mode": parity,
+            "per_module_us": modules, "configs": {"c4": c4},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -513,8 +513,6 @@ __device__ __forceinline__ void node_stage_body(const NodeTable& Tb, f32x4* wrin
     f32x16 xp[2], pq[2];
     xp[0] = load_bias_tile(b1, h);
     xp[1] = load_bias_tile(b1 + 32, h);
-    pq[0] = load_bias_tile(bpq, h);
-    pq[1] = load_bias_tile(bpq + 32, h);
     Parts<P> xi[2][2];
     make_parts_tiles<P, 2>(in, xi, ovf);
     GN_STAMP(unit, 1);
@@ -527,6 +525,8 @@ __device__ __forceinline__ void node_stage_body(const NodeTable& Tb, f32x4* wrin
       }
     });
     GN_STAMP(unit, 2);
+    pq[0] = load_bias_tile(bpq, h);         // (requested here: held across the layer pair they cost 32 registers)
+    pq[1] = load_bias_tile(bpq + 32, h);
     store_rows<2>(reinterpret_cast<T*>(G.xp), GN_FEAT, rb.row, h, rb.live, xp);
     Parts<P> xq[2][2];
     make_parts_tiles<P, 2>(xp, xq, ovf);
@@ -653,11 +653,8 @@ __device__ __forceinline__ void edge_x_body(const GroupTable<gn_edge_group_t>& T
   if constexpr (P == 2) ovf |= image_flag(img, 80);
   ws.begin(img, wring, lane, wave_id(), 80 / WS::CH);
   const f32x16 hidA0 = load_bias_tile(bi0, h);
-  const f32x16 hidB0 = load_bias_tile(bd0, h);
   z[0] = load_bias_tile(bi1, h);
   z[1] = load_bias_tile(bi1 + 32, h);
-  f32x16 lgv[1];
-  lgv[0] = load_bias_tile(bd1, h);
   Parts<P> xi[2][2];
   make_parts_tiles<P, 2>(in, xi, ovf);
   GN_STAMP(unit, 1);
@@ -670,6 +667,10 @@ __device__ __forceinline__ void edge_x_body(const GroupTable<gn_edge_group_t>& T
   });
   GN_STAMP(unit, 2);
   if (G.keep_z != nullptr) store_rows<2>(G.keep_z, GN_FEAT, rb.row, h, rb.live, z);
+  // (the bias tiles of pair B are requested here, not at the top: held across pair A they cost 32 registers — and scratch)
+  const f32x16 hidB0 = load_bias_tile(bd0, h);
+  f32x16 lgv[1];
+  lgv[0] = load_bias_tile(bd1, h);
   make_parts_tiles<P, 2>(z, xi, ovf);
   // ---- pair B: 64 -> 256 -> (logits | factor), 8 hidden tiles x (4 + 2) sub-steps, pipeline order ----
   layer_pair<P, 2, 1, 8, P == 1>(ws, 0, 32, xi, hidB0, bd0, h, lgv, ovf, [&](int t, f32x16& hid) {
@@ -794,6 +795,15 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
   GN_STAMP(unit, 0);
   GN_STAMP(unit, 8);
 
+  // hyper gather from the workgroup's scenes staged in LDS (block-uniform; the stage shares `part` with the partial
+  // sums, which are exchanged behind a barrier at the end)
+  const bool hstage = Tb.g[gi].lines == 2;
+  int hnode0 = 0;
+  if (hstage) {
+    const int rpw = 128 / wpr, r0 = min(wg * rpw, rows - 1);
+    hnode0 = ori_stage_fill<T>(G, r0, min(rows - 1, r0 + rpw - 1), reinterpret_cast<T*>(part_dyn));
+    __syncthreads();
+  }
   bool pair_form = false;
   if constexpr (P != 1) pair_form = G.A != nullptr;
   // (the weight image of this group's form and its flag word)
@@ -979,6 +989,8 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
     f32x16 in[2];
     if (G.eo != nullptr) {
       load_rows<2>(reinterpret_cast<const T*>(G.eo), GN_FEAT, rb.row_ld, h, in);
+    } else if (hstage) {
+      gather_hyper_staged<T>(G, rb.row_ld, h, reinterpret_cast<const T*>(part_dyn), hnode0, in);
     } else if (Tb.g[gi].lines) {
       gather_rows_lines<T>(G, blk, rows, lane, &part[wave][0][0]);
       __builtin_amdgcn_wave_barrier();
@@ -1022,6 +1034,8 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
     f32x16 in[2];
     if (G.eo != nullptr) {
       load_rows<2>(reinterpret_cast<const T*>(G.eo), GN_FEAT, rb.row_ld, h, in);
+    } else if (hstage) {
+      gather_hyper_staged<T>(G, rb.row_ld, h, reinterpret_cast<const T*>(part_dyn), hnode0, in);
     } else if (Tb.g[gi].lines) {
       // (every wave of the row block forms the rows itself, in its own scratch; the partial sums reuse it at the end)
       gather_rows_lines<T>(G, blk, rows, lane, &part[wave][0][0]);

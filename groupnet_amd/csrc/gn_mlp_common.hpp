@@ -240,27 +240,20 @@ __device__ __forceinline__ void fetch_uniforms(const float* __restrict__ U, unsi
     if (f0 < K) {
       const unsigned long long pos0 = base + (unsigned long long)orow * K + f0;
       const int o = (int)(pos0 & 3ull);
-      uint32_t w[8];
-      {
-        uint32_t c[4];
-        gn_philox_block(pos0 >> 2, seed, c);
+      // words 0..6 of the run's (at most two) blocks as NAMED scalars: held in an array, the select of word o + j is
+      // turned into a load at a run-time index by the compiler, i.e. the array lives in scratch memory (32 bytes per
+      // lane, stores and dependent loads in the epilogue of every row of a K > 8 module)
+      uint32_t c0[4], c1[4] = {0u, 0u, 0u, 0u};
+      gn_philox_block(pos0 >> 2, seed, c0);
+      if (o + min(K - f0, 4) > 4) gn_philox_block((pos0 >> 2) + 1ull, seed, c1);     // the run crosses into the next block
+      const bool o1 = (o & 1) != 0, o2 = (o & 2) != 0;
+      // shift by (o & 1), then by (o & 2): word o + j for j = 0..3 in 10 selects
+      const uint32_t s0 = o1 ? c0[1] : c0[0], s1 = o1 ? c0[2] : c0[1], s2 = o1 ? c0[3] : c0[2], s3 = o1 ? c1[0] : c0[3],
+                     s4 = o1 ? c1[1] : c1[0], s5 = o1 ? c1[2] : c1[1];
+      const uint32_t a[4] = {o2 ? s2 : s0, o2 ? s3 : s1, o2 ? s4 : s2, o2 ? s5 : s3};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = c[i];
-      }
-#pragma unroll
-      for (int i = 4; i < 8; ++i) w[i] = 0u;
-      if (o + min(K - f0, 4) > 4) {                         // the run crosses into the next block
-        uint32_t c[4];
-        gn_philox_block((pos0 >> 2) + 1ull, seed, c);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[4 + i] = c[i];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // word o + j of w[0..7]
-        const uint32_t a0 = o == 0 ? w[j] : (o == 1 ? w[j + 1] : (o == 2 ? w[j + 2] : w[j + 3]));
-        if (f0 + j < K) u[4 * g + j] = gn_philox_to_uniform(a0);
-      }
+      for (int j = 0; j < 4; ++j)
+        if (f0 + j < K) u[4 * g + j] = gn_philox_to_uniform(a[j]);
     }
   }
 }
@@ -631,6 +624,33 @@ __device__ __forceinline__ void gather_pair_staged(const gn_agg_group_t& G, int 
   add_row(ob + (size_t)j * PS::kPitch, 1.f, h, a);       // + ori_j  (2 ori_i on the diagonal)
 }
 
+// eo = H ori of a hyper module from the staged rows: the same members in the same (ascending) order and the same fmaf
+// per (row, feature) as weighted_rows — identical bits — with the member rows read from LDS instead of one L2 round trip
+// per batch of members (the per-lane / line-layout gathers kept a hyper wave of the typed aggregation in its prologue
+// for 15 k cycles, a fifth of the launch).  The incidence row (N floats) is requested up front.
+template <typename T>
+__device__ __forceinline__ void gather_hyper_staged(const gn_agg_group_t& G, int row, int h, const T* __restrict__ s_ori,
+                                                    int node0, f32x16 (&a)[2]) {
+  using PS = PoolStage<T>;
+  constexpr int NMAX = 16;
+  const int E = G.E, N = G.N;
+  const int b = row / E;
+  const T* ob = s_ori + (size_t)(b * N - node0) * PS::kPitch;
+  const float* Hrow = G.H + (size_t)row * N;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[t][r] = 0.f;
+  for (int n0 = 0; n0 < N; n0 += NMAX) {
+    float w[NMAX];
+#pragma unroll
+    for (int u = 0; u < NMAX; ++u) w[u] = n0 + u < N ? Hrow[n0 + u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < NMAX; ++u)
+      if (w[u] != 0.f) add_row(ob + (size_t)(n0 + u) * PS::kPitch, w[u], h, a);
+  }
+}
+
 __device__ __forceinline__ void relu_scale16(f32x16& a, float w) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f) * w;
@@ -722,7 +742,8 @@ struct AggGroup {
   gn_agg_group_t a;
   int wpr;
   int stage;   // pair form, wpr == 1: the workgroup stages the per-node pre-activations of its scenes in LDS
-  int lines;   // fused hyper gather accumulated in line layout (agg_x_kernel; needs the launch's `part` LDS)
+  int lines;   // fused hyper gather: 1 = accumulated in line layout (agg_x_kernel; needs the launch's `part` LDS),
+               // 2 = from the scenes' ori rows staged in that LDS (the workgroup's scenes fit)
 };
 
 // eo = H ori of one 32-row block in LINE layout (see scatter_tile_lines in gn_mlp_bf16.hpp for why): lane L = (sub = L / 8,

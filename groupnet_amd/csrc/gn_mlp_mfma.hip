@@ -1140,13 +1140,25 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
   }
   // fused hyper gather in line layout (bf16-core kernels; GN_AGG_LINES = 0 keeps the per-lane gather): needs the LDS too
   const bool no_lines = getenv("GN_AGG_LINES") != nullptr && atoi(getenv("GN_AGG_LINES")) == 0;
+  // ... or, when the scenes of a workgroup's rows fit the LDS, from their ori rows staged there (GN_AGG_HSTAGE = 0
+  // keeps the line-layout gather): lines = 2
+  const bool no_hstage = getenv("GN_AGG_HSTAGE") != nullptr && atoi(getenv("GN_AGG_HSTAGE")) == 0;
+  size_t stage_need = 0;
   for (int g = 0; g < n_groups; ++g) {
     const gn_agg_group_t& a = T.g[g].a;
     T.g[g].lines = (xm && !no_lines && a.A == nullptr && a.eo == nullptr && a.H != nullptr && a.N <= 64) ? 1 : 0;
+    if (T.g[g].lines && !no_hstage) {
+      const int nodes = pool_stage_nodes(128 / T.g[g].wpr, a.E, a.N);
+      const size_t b = (size_t)nodes * (twin ? PoolStage<__bf16>::kPitch * sizeof(__bf16) : PoolStage<float>::kPitch * sizeof(float));
+      if (b <= 44 * 1024) {
+        T.g[g].lines = 2;
+        stage_need = b > stage_need ? b : stage_need;
+      }
+    }
   }
   bool need_part = false;       // LDS for partial sums (wpr > 1), the staged node rows or the line-layout gather
   for (int g = 0; g < n_groups; ++g) need_part = need_part || T.g[g].wpr > 1 || T.g[g].stage != 0 || T.g[g].lines != 0;
-  const size_t part_bytes = need_part ? kAggPartBytes : 0;
+  const size_t part_bytes = need_part ? (stage_need > kAggPartBytes ? stage_need : (size_t)kAggPartBytes) : 0;
   if (twin)
     hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
   else if (xm) {

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 CFG=${1:-c2}
 OUT=gpurun_out/prof_$CFG
 rm -rf $OUT && mkdir -p $OUT
-COMMON="--config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-train-leg"
+COMMON="--config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-train-leg --no-c4-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s1 -- python3 bench.py $COMMON --streams 1 > $OUT/s1_line.json 2> $OUT/s1.err
 echo "s1 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dflt -- python3 bench.py $COMMON > $OUT/dflt_line.json 2> $OUT/dflt.err
