@@ -545,6 +545,12 @@ class _MessagePassing(nn.Module):
         return MSHGNNFunction.apply((self,), (H,), (noise_u,), h, *_plist(self))
 
 
+def _pair_form() -> bool:
+    """Pairwise module, fp32 entry points: first layer of the typed aggregation MLP per NODE in the node stage + pair
+    form (True), or both layers per unordered pair inside the aggregation kernel (False: no `A` tensor)."""
+    return os.environ.get("GN_PAIR_FORM", "1") != "0"
+
+
 def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor], Hs: Sequence[Optional[Tensor]],
                         noises: Sequence, outs: Sequence[Optional[Tensor]], traces=None, join=None
                         ) -> List[Tuple[Tensor, Tensor]]:
@@ -593,7 +599,7 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
         # graph its first layer is linear in the two nodes (eo = ori_i + ori_j) and runs once per NODE, in this
         # same launch (fp32 path; the bf16 twin runs both layers per pair on the matrix cores instead)
         specs = [((m.edge_aggregation_list[idx]._packed(), m.edge_aggregation_list[idx].edge_types)
-                  if (sy and not twin) else None) for m, sy in zip(mods, syms)]
+                  if (sy and not twin and _pair_form()) else None) for m, sy in zip(mods, syms)]
         xpq, As = ops.node_stage_grouped([(x, pk) for x, pk in zip(xs, pks)], keep, specs)
         pair_A[:] = As
         if join is not None and idx == 0:
@@ -635,7 +641,7 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
         eos = dict(zip(standalone, ops.agg_gather_grouped([(oris[i], Hs[i]) for i in standalone]))) if standalone else {}
         for i in range(n):
             pk, K = aggs[i]._packed(), aggs[i].edge_types
-            if syms[i] and not twin:
+            if syms[i] and not twin and pair_A[i] is not None:
                 # pairwise: eo = ori_i + ori_j makes the typed MLP's first layer linear in the two nodes, so
                 # it ran once per node (N rows instead of N(N+1)/2 pairs) in this round's node stage; the
                 # pair form does the rest

@@ -944,6 +944,17 @@ extern "C" int gn_node_mlp_bf16(const gn_node_group_t* groups, int n_groups, int
   return node_stage_launch<1, __bf16>(groups, n_groups, rows, (hipStream_t)stream);
 }
 
+// Row-block pairs from which the bf16-storage edge / aggregation launches run two row blocks per wave (the chip must
+// still be filled: >= 2048 waves).  GN_RB2_MIN_PAIRS is a TEST knob: the parity suite lowers it so that the launcher's
+// own choice falls on those kernels at sizes the CPU oracle can follow (tests/test_bf16_gpu.py).
+static long long rb2_min_pairs() {
+  if (const char* e = getenv("GN_RB2_MIN_PAIRS")) {
+    const long long v = atoll(e);
+    if (v > 0) return v;
+  }
+  return 2048;
+}
+
 // ---- edge MLP --------------------------------------------------------------------------------------------------
 static int edge_launch(const gn_edge_group_t* groups, int n_groups, float tau, unsigned long long seed,
                        const unsigned long long* offset_dev, hipStream_t stream, bool twin) {
@@ -1002,7 +1013,7 @@ static int edge_launch(const gn_edge_group_t* groups, int n_groups, float tau, u
     // a large launch: two row blocks per wave (edge_rb2_kernel); GN_EDGE_RB2 = 0 / 1 forces the choice (parity tests)
     long long pairs = 0;
     for (int g = 0; g < n_groups; ++g) pairs += ((groups[g].rows + 31) / 32 + 1) / 2;
-    bool rb2 = pairs >= 2048;
+    bool rb2 = pairs >= rb2_min_pairs();
     if (const char* e = getenv("GN_EDGE_RB2")) rb2 = atoi(e) != 0;
     if (rb2) {
       wg = 0;
@@ -1116,7 +1127,7 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
     // the parity tests run small cases through both kernels)
     long long pairs = 0;
     for (int g = 0; g < n_groups; ++g) pairs += ((groups[g].rows + 31) / 32 + 1) / 2;
-    bool rb2 = pairs >= 2048;
+    bool rb2 = pairs >= rb2_min_pairs();
     if (const char* e = getenv("GN_AGG_RB2")) rb2 = atoi(e) != 0;
     if (rb2) {
       wg = 0;

@@ -23,9 +23,10 @@ class ReluProbe:
         self.units = 0
 
     def see(self, x: torch.Tensor) -> None:
-        if x.dim() >= 2 and x.shape[0] == self.near.shape[0]:
-            self.near = torch.minimum(self.near, x.detach().abs().reshape(x.shape[0], -1).min(dim=1).values)
-            self.units += x[0].numel()
+        B = self.near.shape[0]
+        if x.dim() >= 2 and x.shape[0] % B == 0:      # (B, ...) or scene-major rows (B*N, ...)
+            self.near = torch.minimum(self.near, x.detach().abs().reshape(B, -1).min(dim=1).values)
+            self.units += x.numel() // B
 
     def clean(self) -> torch.Tensor:
         """(B,) bool: no ReLU input of the scene lies within WINDOW of zero."""

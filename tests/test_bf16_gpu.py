@@ -11,8 +11,9 @@ the measured values printed by every test:
   * incidence H: BIT-EXACT against the oracle fed the same bf16-rounded agent features (affinity and ranking
     run in fp32 on those values; rows whose k-th / (k+1)-th affinity gap is below 1e-5 are excluded, as in the
     fp32 tests, because torch.topk's tie order is unspecified — their share is asserted to be < 0.5 %);
-  * features and edge-type distributions: |twin - fp32 oracle| <= 1.5e-2 * max|oracle| (measured 3e-3 .. 4.5e-3),
-    and <= 1.5e-2 of the same scale against the library's own fp32 path on identical (bf16-representable) inputs;
+  * features and edge-type distributions: |twin - fp32 oracle| <= 8e-3 * max|oracle| (measured 3e-3 .. 4.5e-3: the
+    gate leaves room for less than one more bf16 rounding step, 2^-9 x a fan-in factor, not for a lost one),
+    and <= 8e-3 of the same scale against the library's own fp32 path on identical (bf16-representable) inputs;
   * byte-moving stages (gather, scatter): the twin equals the fp32 kernel's result rounded once to bf16, bit for
     bit — same summation order, one final rounding.
 """
@@ -24,8 +25,8 @@ from oracle import ms_hgnn_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-TOL_ORACLE = 1.5e-2   # of max|oracle feature| (measured 3e-3 .. 4.5e-3), see module docstring
-TOL_FP32PATH = 1.5e-2
+TOL_ORACLE = 8e-3     # of max|oracle feature| (measured 3e-3 .. 4.5e-3), see module docstring
+TOL_FP32PATH = 8e-3
 GAP = 1e-5            # minimum k-th / (k+1)-th affinity gap for a row's H to be compared bit for bit
 
 
@@ -58,13 +59,19 @@ def safe_rows(corr, scale):
 
 
 @pytest.mark.parametrize("B,N,scales,rb2", [(6, 11, [2, 5, 11], None), (2, 50, [2, 4, 8, 16], "0"),
-                                             (2, 50, [2, 4, 8, 16], "1"), (3, 50, [2, 4, 8, 16], "1")])
+                                             (2, 50, [2, 4, 8, 16], "1"), (3, 50, [2, 4, 8, 16], "1"),
+                                             (3, 50, [2, 4, 8, 16], "auto")])
 def test_bf16_block_matches_fp32_oracle(B, N, scales, rb2, monkeypatch):
     """The whole multiscale block on bf16 storage vs the fp32 oracle (decomposed attention) on the same
     bf16-rounded agent features and the same uniforms.  N=50 / scales {2,4,8,16} is BASELINE config 4's shape;
     rb2 forces the edge MLP and the typed aggregation MLP through their one-row-block ("0") or two-row-blocks-per-wave ("1") kernels
     (the launcher picks the latter by itself only at sizes the oracle cannot reach; B=3: ragged last block pair)."""
-    if rb2 is not None:
+    if rb2 == "auto":
+        # the launcher's OWN choice of the two-row-blocks kernels (row-block pairs >= threshold), with the threshold
+        # lowered by the test knob GN_RB2_MIN_PAIRS so that it is met at a size the oracle can follow (config 4 itself
+        # has 20 k pairs against the default 2048)
+        monkeypatch.setenv("GN_RB2_MIN_PAIRS", "16")
+    elif rb2 is not None:
         monkeypatch.setenv("GN_AGG_RB2", rb2)
         monkeypatch.setenv("GN_EDGE_RB2", rb2)
     blk, sp, shs = block_and_states(scales, seed=11)
@@ -95,6 +102,17 @@ def test_bf16_block_matches_fp32_oracle(B, N, scales, rb2, monkeypatch):
     print(f"\nbf16 twin vs fp32 oracle, B={B} N={N} scales={scales}: max rel err per module "
           f"{['%.2e' % e for e in errs]} (gate {TOL_ORACLE:g}); near-tie rows {unsafe}/{total}")
     assert max(errs) <= TOL_ORACLE
+    if rb2 == "auto":
+        # it really was the launcher's pick of the rb2 kernels: bit-identical to forcing them, different from forcing
+        # the one-row-block kernels
+        nd = [[u.to(dev()) for u in n] for n in noise]
+        res = {}
+        for force in ("1", "0"):
+            monkeypatch.setenv("GN_AGG_RB2", force)
+            monkeypatch.setenv("GN_EDGE_RB2", force)
+            with torch.no_grad():
+                res[force] = blk(h.to(dev()), noise_u=nd)[0].clone()
+        assert torch.equal(out, res["1"]) and not torch.equal(out, res["0"])
 
 
 def test_bf16_modules_return_reference_shaped_tuples():
