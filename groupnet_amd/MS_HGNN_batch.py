@@ -538,10 +538,19 @@ class _MessagePassing(nn.Module):
     def _forward_autograd(self, h: Tensor, H: Optional[Tensor], noise_u, out: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
         """Training path: fused forward + HIP backward through torch.autograd."""
         from .backward import MSHGNNFunction
-        if h.dtype != torch.float32:
-            raise NotImplementedError("the bf16 twins are forward-only: run them under torch.no_grad()")
         if out is not None:
             raise ValueError("out= is an inference-time extra; under autograd the module returns a new tensor")
+        if h.dtype == torch.bfloat16:
+            # bf16 activations under autograd (config 4's storage type in training): the twins' kernels are
+            # forward-only, so the training step runs the fp32 training path on the up-cast inputs — forward values
+            # then carry fp32 intermediates (within the twins' own tolerance of them), gradients are those of the fp32
+            # function at the bf16-rounded inputs, and outputs / the input gradient come back in bf16 (the casts are
+            # ordinary differentiable torch ops).
+            nf, fac = MSHGNNFunction.apply((self,), (None if H is None else H.float(),), (noise_u,), h.float(),
+                                           *_plist(self))
+            return nf.to(torch.bfloat16), fac.to(torch.bfloat16)
+        if h.dtype != torch.float32:
+            raise NotImplementedError("activations must be fp32 or bf16")
         return MSHGNNFunction.apply((self,), (H,), (noise_u,), h, *_plist(self))
 
 

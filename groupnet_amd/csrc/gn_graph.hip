@@ -927,6 +927,102 @@ __global__ __launch_bounds__(kBlock) void agg_scatter_direct_kernel(const TS* __
   }
 }
 
+// Pairwise scatter over unordered pairs, every pair row read ONCE (agg_scatter_direct_kernel<2> fetches each row for
+// both of its member nodes: measured 326 MB of HBM traffic for 187 MB of algorithmic bytes at N = 50, B = 1024, bf16 —
+// the launch sits at the HBM roof, so the second fetch is paid in full).  A workgroup owns a scene: the scene's
+// N(N+1)/2 pair rows are contiguous in HBM and stream through LDS in bands of kPairBand rows (coalesced 16-byte pieces,
+// the next band's loads in flight while the current one is consumed: two buffers); thread t owns the items
+// (node n, 4 features d) with n*16 + d = t, t + 256, ... and adds, band by band, the rows of the band that contain n —
+// rows (i, n), i < n, have increasing pair indices and all precede the contiguous run (n, n .. N-1), so a cursor per
+// item walks them in the order j = 0 .. N-1 of the direct kernel: identical sums, bit for bit.
+constexpr int kPairBand = 128;        // pair rows per band
+constexpr int kPairItems = 4;         // (node, 4 features) items per thread: N * 16 <= 256 * kPairItems  ->  N <= 64
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void agg_scatter_pairs_kernel(const TS* __restrict__ feat, const TS* __restrict__ ori,
+                                                                   TS* __restrict__ out, int N, float fN) {
+  constexpr int kPiece = 16 / (int)sizeof(TS);                 // elements per 16-byte piece
+  constexpr int kRowPieces = GN_FEAT / kPiece;                 // pieces per pair row
+  constexpr int kLoads = kPairBand * kRowPieces / kBlock;      // pieces per thread and band (fp32: 8, bf16: 4)
+  __shared__ __align__(16) TS band[2][kPairBand * GN_FEAT];
+  const int b = blockIdx.x;
+  const int P = gn_pair_count(N);
+  const f32x4* src = reinterpret_cast<const f32x4*>(feat + (size_t)b * P * GN_FEAT);
+  const int total_pieces = P * kRowPieces;
+  f32x4 acc[kPairItems];
+  int nn[kPairItems], dd[kPairItems], cur[kPairItems];        // node, feature quad, next partner i < n
+#pragma unroll
+  for (int u = 0; u < kPairItems; ++u) {
+    const int idx = (int)threadIdx.x + u * kBlock;
+    nn[u] = idx < N * 16 ? idx >> 4 : -1;
+    dd[u] = idx & 15;
+    cur[u] = 0;
+    acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 st[kLoads];
+  auto fetch = [&](int band_i) {
+#pragma unroll
+    for (int it = 0; it < kLoads; ++it) {
+      const int pc = band_i * (kPairBand * kRowPieces) + (int)threadIdx.x + it * kBlock;
+      st[it] = src[min(pc, total_pieces - 1)];
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < kLoads; ++it)
+      reinterpret_cast<f32x4*>(band[buf])[(int)threadIdx.x + it * kBlock] = st[it];
+  };
+  const int n_bands = (P + kPairBand - 1) / kPairBand;
+  fetch(0);
+  commit(0);
+  if (n_bands > 1) fetch(1);
+  __syncthreads();
+  for (int bi = 0; bi < n_bands; ++bi) {
+    const int r0 = bi * kPairBand, r1 = min(P, r0 + kPairBand);
+    const TS* rows = band[bi & 1];
+#pragma unroll
+    for (int u = 0; u < kPairItems; ++u) {
+      const int n = nn[u];
+      if (n < 0) continue;
+      const TS* col = rows + 4 * dd[u];
+      // rows (i, n), i < n, that fall into this band
+      int i = cur[u];
+      while (i < n) {
+        const int p = gn_pair_start(i, N) + (n - i);
+        if (p >= r1) break;
+        const f32x4 v = ld4(col + (size_t)(p - r0) * GN_FEAT);
+        acc[u][0] += v[0], acc[u][1] += v[1], acc[u][2] += v[2], acc[u][3] += v[3];
+        ++i;
+      }
+      cur[u] = i;
+      // the run (n, j), j = n .. N-1: pair indices ps .. ps + N - 1 - n
+      if (i == n) {
+        const int ps = gn_pair_start(n, N);
+        const int lo = max(ps, r0), hi = min(ps + N - n, r1);
+        for (int p = lo; p < hi; ++p) {
+          const f32x4 v = ld4(col + (size_t)(p - r0) * GN_FEAT);
+          acc[u][0] += v[0], acc[u][1] += v[1], acc[u][2] += v[2], acc[u][3] += v[3];
+        }
+      }
+    }
+    if (bi + 1 < n_bands) {
+      commit((bi + 1) & 1);                       // (that buffer was last read during band bi - 1: behind a barrier)
+      if (bi + 2 < n_bands) fetch(bi + 2);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < kPairItems; ++u) {
+    const int n = nn[u];
+    if (n < 0) continue;
+    const size_t row = (size_t)b * N + n;
+    const f32x4 r = {acc[u][0] / fN, acc[u][1] / fN, acc[u][2] / fN, acc[u][3] / fN};
+    st4(out + row * 2 * GN_FEAT + 4 * dd[u], r);
+    const f32x4 o = ld4(ori + row * GN_FEAT + 4 * dd[u]);
+    const f32x4 ro = {o[0] / fN, o[1] / fN, o[2] / fN, o[3] / fN};
+    st4(out + row * 2 * GN_FEAT + GN_FEAT + 4 * dd[u], ro);
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // Exhaustive hyperedge search (init_adj_attention_listall, model/MS_HGNN_batch.py:390-414): hyperedge i =
 // the group of s agents containing i with the largest total affinity sum_{a,b in group} corr[a][b].
@@ -1410,7 +1506,12 @@ static int scatter_launch(const gn_scatter_group_t* groups, int n_groups, int B,
     const TS* feat = reinterpret_cast<const TS*>(G.feat);
     const TS* ori = reinterpret_cast<const TS*>(G.ori);
     TS* out = reinterpret_cast<TS*>(G.out);
-    if (G.H == nullptr && G.sym) {
+    if (G.H == nullptr && G.sym && N * 16 <= kBlock * kPairItems && B >= 256 &&
+        !(getenv("GN_SCATTER_PAIRS") && atoi(getenv("GN_SCATTER_PAIRS")) == 0)) {
+      // one workgroup per scene, every pair row read once (enough scenes to fill the chip; GN_SCATTER_PAIRS = 0 keeps
+      // the direct kernel: parity tests run both)
+      hipLaunchKernelGGL((agg_scatter_pairs_kernel<TS>), dim3(B), dim3(kBlock), 0, s, feat, ori, out, N, divisor);
+    } else if (G.H == nullptr && G.sym) {
       hipLaunchKernelGGL((agg_scatter_direct_kernel<2, TS>), dim3(capped_grid(total4, kBlock)), dim3(kBlock), 0, s,
                          feat, G.H, ori, out, N, G.E, total4, divisor);
     } else if (G.H == nullptr) {

@@ -112,8 +112,16 @@ class MultiScaleHGNN(nn.Module):
         S = len(self.hyper_scales)
         nmp = self.interaction.nmp_layers
         if _needs_grad(self, f):
+            if f.dtype == torch.bfloat16:
+                # bf16 storage under autograd: the fp32 training path on the up-cast features, results back in bf16
+                # (see MS_HGNN_batch._forward_autograd) — config 4 can train, with fp32 intermediates
+                if advance:
+                    ops.counter_add(advance[0], advance[1])
+                out, new_H = multiscale_autograd(self.interaction, list(self.interaction_hyper), self.hyper_scales,
+                                                 f.float(), noise_u)
+                return out.to(torch.bfloat16), (None if new_H is None else new_H.to(torch.bfloat16))
             if f.dtype != torch.float32:
-                raise NotImplementedError("the bf16 twins are forward-only: run them under torch.no_grad()")
+                raise NotImplementedError("activations must be fp32 or bf16")
             # training: ONE autograd node for the 1+S modules (grouped fused forward, grouped HIP backward);
             # the concat is an ordinary differentiable torch.cat
             if advance:

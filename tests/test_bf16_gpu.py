@@ -200,14 +200,42 @@ def test_bf16_fused_affinity_topk_ranks_in_fp32():
     assert torch.equal(final[..., :64], f)
 
 
-def test_bf16_twins_are_forward_only():
+def test_bf16_activations_train_through_the_fp32_path():
+    """bf16 activations under autograd (config 4's storage type in a training step): the twins' kernels are forward-only,
+    so the call runs the fp32 training path on the up-cast inputs and returns bf16 — outputs within the twins' tolerance
+    of the no-grad twin forward, gradients equal to the fp32 block's gradients at the same (bf16-representable) inputs
+    up to the one bf16 rounding of the output / input-gradient casts."""
     blk, _, _ = block_and_states([2, 11], seed=1)
-    h = torch.randn(4, 11, 64, device=dev()).bfloat16()
-    with pytest.raises(NotImplementedError):
-        blk(h)                                   # parameters require grad and autograd is recording
+    B, N = 4, 11
+    h = torch.randn(B, N, 64, device=dev()).bfloat16()
+    noise = [[torch.rand(s, device=dev())] for s in blk.noise_shapes(B, N)]
     with torch.no_grad():
-        out, _ = blk(h)
-    assert out.dtype == torch.bfloat16
+        twin, _ = blk(h, noise_u=noise)
+    blk.train()
+    x16 = h.clone().requires_grad_(True)
+    out16, H16 = blk(x16, noise_u=noise)
+    assert out16.dtype == torch.bfloat16 and out16.requires_grad and H16.dtype == torch.bfloat16
+    scale = float(twin.float().abs().max())
+    assert float((out16.float() - twin.float()).abs().max()) <= TOL_FP32PATH * scale
+    R = torch.randn_like(out16.float()).bfloat16().float()      # bf16-representable: the casts' backward keeps it exact
+    (out16.float() * R).sum().backward()
+    g16 = {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None}
+    gx16 = x16.grad.clone()
+    blk.zero_grad()
+    x32 = h.float().requires_grad_(True)
+    out32, _ = blk(x32, noise_u=noise)
+    (out32 * R).sum().backward()
+    assert gx16.dtype == torch.bfloat16
+    assert float((gx16.float() - x32.grad).abs().max()) <= 2.0 ** -8 * float(x32.grad.abs().max())      # one bf16 rounding
+    worst = 0.0
+    for k, p in blk.named_parameters():
+        if p.grad is None:
+            continue
+        sc = max(float(p.grad.abs().max()), 1e-30)
+        worst = max(worst, float((g16[k] - p.grad).abs().max()) / sc)
+    print(f"\nbf16 training call vs fp32 block: worst parameter-gradient difference {worst:.2e} of its scale")
+    assert worst <= 1e-6      # same fp32 graph, same upstream gradient: only the returned tensors were cast
+    blk.eval()
 
 
 def test_config4_full_size_properties_bf16():
