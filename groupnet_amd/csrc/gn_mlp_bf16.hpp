@@ -85,7 +85,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float kF16Limit = 65000.f;      // an operand beyond this sends the workgroup to the bf16x6 path
-typedef unsigned long long ovf_t;         // lanes that have split a value beyond kF16Limit (wave-uniform, in SGPRs)
+// Range state of a wave on the fp16 path: `mask` = lanes that have split a value beyond kF16Limit (wave-uniform, in
+// SGPRs), `wf` = the weight image's flag word as loaded (NOT waited for until the vote at the end of the chain: a wait at
+// the point of the load is a full L2 round trip in the prologue of every kernel).
+struct ovf_t {
+  unsigned long long mask;
+  int wf;
+};
 template <int P>
 __device__ __forceinline__ void make_parts(const f32x16& v, int hf, Parts<P>& x, ovf_t& ovf) {
 #ifdef GN_DIAG_NO_SPLIT      // diagnostic builds only: what the kernels take without the VALU splitting work
@@ -125,7 +131,7 @@ __device__ __forceinline__ void make_parts(const f32x16& v, int hf, Parts<P>& x,
     x.p[0] = __builtin_bit_cast(bf16x8, hi);
     x.p[1] = __builtin_bit_cast(bf16x8, lo);
 #ifndef GN_NO_OVF
-    ovf |= __builtin_amdgcn_ballot_w64(__builtin_fmaxf(__builtin_fmaxf(m[0], m[1]), __builtin_fmaxf(m[2], m[3])) > kF16Limit);
+    ovf.mask |= __builtin_amdgcn_ballot_w64(__builtin_fmaxf(__builtin_fmaxf(m[0], m[1]), __builtin_fmaxf(m[2], m[3])) > kF16Limit);
 #endif
   }
   if constexpr (P == 1) x.p[0] = cvt_half(v, hf);
@@ -169,12 +175,12 @@ constexpr int kMfmaPerSub = P == 3 ? 6 : (P == 2 ? 3 : 1);
 // a workgroup share one weight stream (and its barriers).  Every wave of the workgroup must return from `body`.
 template <int P, typename F>
 __device__ __forceinline__ void run_with_fallback(F body) {
-  ovf_t ovf = 0ull;
+  ovf_t ovf = {0ull, 0};
   if constexpr (P == 2) {
     body(std::integral_constant<int, 2>{}, ovf);
-    if (!__syncthreads_or(ovf != 0ull)) return;
+    if (!__syncthreads_or(ovf.mask != 0ull || ovf.wf != 0)) return;
 #ifndef GN_NO_FALLBACK       // (diagnostic builds: the fp16 path alone)
-    ovf = 0ull;
+    ovf = {0ull, 0};
     body(std::integral_constant<int, 3>{}, ovf);
 #endif
   } else {
@@ -183,9 +189,8 @@ __device__ __forceinline__ void run_with_fallback(F body) {
 }
 // The flag word behind an fp16 weight image of `substeps` sub-steps (gn_split_f16_f32 sets it when a weight does not
 // fit fp16): nonzero sends the workgroup to the bf16x6 path.
-__device__ __forceinline__ ovf_t image_flag(const void* image, int substeps) {
-  const int f = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(image) + (size_t)substeps * 2 * 1024);
-  return gn_uniform(f) != 0 ? ~0ull : 0ull;
+__device__ __forceinline__ int image_flag(const void* image, int substeps) {
+  return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(image) + (size_t)substeps * 2 * 1024);
 }
 // the image a group's chain walks with P parts (f16x3: `h`, bf16x6 / twins: `x`)
 template <int P>
@@ -264,7 +269,13 @@ struct XStream {
 //                 chunk c+2+LOOK : global -> staging registers
 // Requirements: all 4 waves of the workgroup call begin / step / skip with identical arguments (no early exits);
 // segment lengths are multiples of CH * LOOK sub-steps wherever the chunk index is not a compile-time constant.
-template <int P, int LOOK_ = (P == 1 ? 4 : 2)>
+#ifndef GN_LOOK2
+#define GN_LOOK2 2
+#endif
+#ifndef GN_QD2
+#define GN_QD2 2
+#endif
+template <int P, int LOOK_ = (P == 1 ? 4 : (P == 2 ? GN_LOOK2 : 2)), int QD_ = (P == 1 ? 4 : (P == 2 ? GN_QD2 : 2))>
 struct WStream {
   static constexpr int CH = P == 1 ? 8 : 4;      // sub-steps per chunk
   static constexpr int LOOK = LOOK_;             // chunks between a piece's global load and its LDS write (the kernels
@@ -274,7 +285,7 @@ struct WStream {
   static constexpr int PW = PIECES / 4;          // pieces each of the 4 waves stages per chunk
   static constexpr int kChunkF4 = PIECES * 64;   // f32x4 elements of a chunk
   static constexpr int kRingF4 = R * kChunkF4;   // ... of the ring (36 KiB / 24 KiB)
-  static constexpr int QD = P == 1 ? 4 : 2;      // operand registers: sub-steps read ahead of their MFMA + 1.  A P = 3
+  static constexpr int QD = QD_;                 // operand registers: sub-steps read ahead of their MFMA + 1.  A P = 3
                                                  // sub-step is 192 cycles of matrix work — one ahead covers the LDS
                                                  // latency; a P = 1 sub-step is 32 cycles, so three ahead
   // Running state instead of index arithmetic per access (a P = 1 sub-step is ONE 32-cycle MFMA: a handful of
@@ -505,7 +516,7 @@ __device__ __forceinline__ void node_stage_body(const NodeTable& Tb, f32x4* wrin
     const float* b1 = G.bias + 256;
     const float* bpq = G.bias + 320;
     const void* img = pick_image<P>(G.Wx, G.Wh);
-    if constexpr (P == 2) ovf |= image_flag(img, 72);
+    if constexpr (P == 2) ovf.wf |= image_flag(img, 72);
     ws.begin(img, wring, lane, wave, 72 / WS::CH);
     f32x16 in[2];
     load_rows<2>(reinterpret_cast<const T*>(G.x), GN_FEAT, rb.row_ld, h, in);
@@ -557,7 +568,7 @@ __device__ __forceinline__ void node_stage_body(const NodeTable& Tb, f32x4* wrin
   const int nt = min(kATiles, OTA - o0);                 // a multiple of 4
   // 4 sub-steps per output tile; the stream of this workgroup starts at tile o0 of the image
   const void* imgA = pick_image<P>(G.WAx, G.WAh);
-  if constexpr (P == 2) ovf |= image_flag(imgA, OTA * 4);
+  if constexpr (P == 2) ovf.wf |= image_flag(imgA, OTA * 4);
   ws.begin(reinterpret_cast<const f32x4*>(imgA) + (size_t)o0 * 4 * P * 64, wring, lane, wave, (OTA - o0) * 4 / WS::CH);
   f32x16 in[2];
   load_rows<2>(reinterpret_cast<const T*>(G.x), GN_FEAT, rb.row_ld, h, in);
@@ -650,7 +661,7 @@ __device__ __forceinline__ void edge_x_body(const GroupTable<gn_edge_group_t>& T
   const float* bd1 = G.bias + 448;
   WS ws;
   const void* img = pick_image<P>(G.Wx, G.Wh);
-  if constexpr (P == 2) ovf |= image_flag(img, 80);
+  if constexpr (P == 2) ovf.wf |= image_flag(img, 80);
   ws.begin(img, wring, lane, wave_id(), 80 / WS::CH);
   const f32x16 hidA0 = load_bias_tile(bi0, h);
   z[0] = load_bias_tile(bi1, h);
@@ -808,7 +819,7 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
   if constexpr (P != 1) pair_form = G.A != nullptr;
   // (the weight image of this group's form and its flag word)
   const void* img = pair_form ? pick_image<P>(G.W2x, G.W2h) : pick_image<P>(G.W12x, G.W12h);
-  if constexpr (P == 2) ovf |= image_flag(img, pair_form ? K * 16 : K * 32);
+  if constexpr (P == 2) ovf.wf |= image_flag(img, pair_form ? K * 16 : K * 32);
   if (pair_form && wpr == 1) {
     // ---- pair form: hid_t = relu(A_i + A_j) * ef_k is VALU work (V_t), its layer-2 slice the matrix work (B_t:
     // one chunk of the stream, 16 sub-steps per type).  wpr == 1, pipelined: V of the NEXT tile (the next type's
@@ -1129,7 +1140,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void agg_rb2_kernel(GroupTable<AggGroup> Tb, int stage_bytes) {
   constexpr int RB = 2;
   using WS = WStream<1, 2>;
-  ovf_t ovf_unused = 0ull;      // (the range vote belongs to the two-part fp16 path)
+  ovf_t ovf_unused = {0ull, 0};      // (the range vote belongs to the two-part fp16 path)
   __shared__ f32x4 wring[WS::kRingF4];
   extern __shared__ __align__(16) unsigned char ori_dyn[];      // staged ori rows of the pairwise gather
   const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
@@ -1277,7 +1288,7 @@ __global__ __launch_bounds__(256, 2) void edge_rb2_kernel(GroupTable<gn_edge_gro
                                                           const unsigned long long* __restrict__ offset_dev, int pool_bytes) {
   constexpr int RB = 2;
   using WS = WStream<1, 2>;
-  ovf_t ovf_unused = 0ull;      // (the range vote belongs to the two-part fp16 path)
+  ovf_t ovf_unused = {0ull, 0};      // (the range vote belongs to the two-part fp16 path)
   __shared__ f32x4 wring[WS::kRingF4];
   extern __shared__ __align__(16) unsigned char pool_dyn[];      // staged x' / pq rows of the pairwise pooling
   const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
@@ -1543,7 +1554,7 @@ __device__ __forceinline__ void mlp2_x_body(const GroupTable<gn_mlp2_group_t>& T
     f32x16 in[IT];
     mlp2_rows<IT, T>(G, rb.row_ld, h, N, divisor, in);
     const void* img = pick_image<P>(G.Wx, G.Wh);
-    if constexpr (P == 2) ovf |= image_flag(img, kSub);
+    if constexpr (P == 2) ovf.wf |= image_flag(img, kSub);
     ws.begin(img, wring, lane, wave_id(), kSub / WS::CH);
     if (G.in_out != nullptr) store_rows<IT>(G.in_out, 32 * IT, rb.row, h, rb.live, in);   // kept for the backward
     make_parts_tiles<P, IT>(in, xi, ovf);
@@ -1689,35 +1700,38 @@ __device__ __forceinline__ void mlp2_rows_tile(const gn_mlp2_group_t& G, int row
 // layout changes once, through `scratch` (32 rows x 36 floats, private to the wave: write, barrier, read).
 // Returns false (nothing done) for shapes the per-lane form handles (ordered pairwise edges).
 constexpr int kLinePitch = 36;
-template <typename T, bool hyper>
+// NRG row groups (of 8 rows) starting at rg0: the whole tile (rg0 = 0, NRG = 4: one wave per tile), or half of it
+// (NRG = 2: two waves per tile — half the loads per wave, so ALL members of a row fit one batch of requests: one L2
+// round trip instead of two for the N = 11 graphs)
+template <typename T, bool hyper, int NRG>
 __device__ __forceinline__ void scatter_tile_lines_(const gn_mlp2_group_t& G, int blk, int rows, int N, float divisor,
-                                                    int tile, int lane, float* __restrict__ scratch) {
+                                                    int tile, int lane, int rg0, float* __restrict__ scratch) {
   const int E = G.E;
   const int sub = lane >> 3, piece = lane & 7;
   const int cnt = hyper ? E : N;
-  unsigned fo[4], ho[4];                         // feat / H offsets (elements) of this lane's four rows
-  int nn[4];
+  unsigned fo[NRG], ho[NRG];                     // feat / H offsets (elements) of this lane's rows
+  int nn[NRG];
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) {
-    const int r = min(blk * 32 + rg * 8 + sub, rows - 1);
+  for (int rg = 0; rg < NRG; ++rg) {
+    const int r = min(blk * 32 + (rg0 + rg) * 8 + sub, rows - 1);
     const int b = r / N;
     nn[rg] = r - b * N;
     fo[rg] = (unsigned)b * E * GN_FEAT + 32 * tile + 4 * piece;
     ho[rg] = (unsigned)b * E * N + nn[rg];
   }
   const T* feat = reinterpret_cast<const T*>(G.feat);
-  f32x4 acc[4];
+  f32x4 acc[NRG];
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int MB = 6;                          // members per batch (their rows are requested together)
+  for (int rg = 0; rg < NRG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int MB = NRG == 4 ? 6 : 11;          // members per batch (their rows are requested together)
   for (int m0 = 0; m0 < cnt; m0 += MB) {
-    f32x4 v[MB][4];
-    float w[MB][hyper ? 4 : 1];
+    f32x4 v[MB][NRG];
+    float w[MB][hyper ? NRG : 1];
 #pragma unroll
     for (int u = 0; u < MB; ++u) {
       const int m = min(m0 + u, cnt - 1);
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
+      for (int rg = 0; rg < NRG; ++rg) {
         const int idx = hyper ? m : gn_pair_index(nn[rg], m, N);
         v[u][rg] = ld4(feat + fo[rg] + (size_t)idx * GN_FEAT);
         if constexpr (hyper) w[u][rg] = G.H[ho[rg] + (size_t)m * N];
@@ -1727,24 +1741,24 @@ __device__ __forceinline__ void scatter_tile_lines_(const gn_mlp2_group_t& G, in
     for (int u = 0; u < MB; ++u)
       if (m0 + u < cnt) {
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
+        for (int rg = 0; rg < NRG; ++rg)
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[rg][c] = fmaf(hyper ? w[u][hyper ? rg : 0] : 1.f, v[u][rg][c], acc[rg][c]);
       }
   }
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) {
+  for (int rg = 0; rg < NRG; ++rg) {
     f32x4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = acc[rg][c] / divisor;
-    *reinterpret_cast<f32x4*>(scratch + (rg * 8 + sub) * kLinePitch + 4 * piece) = o;
+    *reinterpret_cast<f32x4*>(scratch + ((rg0 + rg) * 8 + sub) * kLinePitch + 4 * piece) = o;
   }
 }
-template <typename T>
+template <typename T, int NRG = 4>
 __device__ __forceinline__ bool scatter_tile_lines(const gn_mlp2_group_t& G, int blk, int rows, int N, float divisor,
-                                                   int tile, int lane, float* __restrict__ scratch) {
-  if (G.H != nullptr) scatter_tile_lines_<T, true>(G, blk, rows, N, divisor, tile, lane, scratch);
-  else if (G.sym) scatter_tile_lines_<T, false>(G, blk, rows, N, divisor, tile, lane, scratch);
+                                                   int tile, int lane, float* __restrict__ scratch, int rg0 = 0) {
+  if (G.H != nullptr) scatter_tile_lines_<T, true, NRG>(G, blk, rows, N, divisor, tile, lane, rg0, scratch);
+  else if (G.sym) scatter_tile_lines_<T, false, NRG>(G, blk, rows, N, divisor, tile, lane, rg0, scratch);
   else return false;
   return true;
 }
@@ -1827,7 +1841,7 @@ __device__ __forceinline__ void mlp2_xs_body(const GroupTable<gn_mlp2_group_t>& 
   const float* b0 = G.bias;
   const float* b1 = G.bias + 32 * HT;
   const void* image = pick_image<P>(G.Wx, G.Wh);
-  if constexpr (P == 2) ovf |= image_flag(image, HT * (NA + NB));
+  if constexpr (P == 2) ovf.wf |= image_flag(image, HT * (NA + NB));
   const f32x4* img = reinterpret_cast<const f32x4*>(image) + lane;
   const f32x4* segA[TPW];
   const f32x4* segB[TPW];
@@ -1844,17 +1858,22 @@ __device__ __forceinline__ void mlp2_xs_body(const GroupTable<gn_mlp2_group_t>& 
   PStream<P, L> ps;
   // fused scatter (IT == 4, waves 0 / 1): accumulated in line layout, handed over through `lines`
   bool via_lines = false;
+  f32x16 in;
   if constexpr (IT == 4) {
     if (G.x == nullptr) {
-      if (wave < 2) via_lines = scatter_tile_lines<T>(G, lwg - Tb.first_wg[gi], rows, N, divisor, wave, lane, lines[wave]);
-      else via_lines = G.H != nullptr || G.sym != 0;
-      if (via_lines) __syncthreads();          // (block-uniform: the group's shape decides)
+      // all four waves gather: wave w takes rows [16 (w >> 1), 16 (w >> 1) + 16) of feature tile w & 1 (the two halves of a
+      // tile meet in `lines`); waves 2 / 3 request their ori tiles first, so those loads fly beside the gather
+      via_lines = G.H != nullptr || G.sym != 0;      // (block-uniform: the group's shape decides)
+      if (via_lines) {
+        if (wave >= 2) mlp2_rows_tile<T>(G, rb.row_ld, h, N, divisor, IT, wave, in);
+        scatter_tile_lines<T, 2>(G, lwg - Tb.first_wg[gi], rows, N, divisor, wave & 1, lane, lines[wave & 1], 2 * (wave >> 1));
+        __syncthreads();
+      }
     }
   }
   if (wave < IT) {
-    f32x16 in;
     if (via_lines && wave < 2) read_tile_lines(lines[wave], lane, in);
-    else mlp2_rows_tile<T>(G, rb.row_ld, h, N, divisor, IT, wave, in);
+    else if (!(via_lines && wave >= 2)) mlp2_rows_tile<T>(G, rb.row_ld, h, N, divisor, IT, wave, in);
     ps.begin(at);       // (behind the gather, whose batches of member rows need the registers; in flight across the exchange)
     if (G.in_out != nullptr && rb.live) store_tile(G.in_out + (size_t)rb.row * (32 * IT) + 32 * wave + 4 * h, in);
     put_parts<P>(lds, wave, lane, in, ovf);
