@@ -440,6 +440,9 @@ def main():
                          "captured graph and output buffers), so the tail of one step overlaps the head of the next")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the training-step side measurement")
     ap.add_argument("--no-c4-leg", action="store_true", help="skip the short BASELINE-config-4 side leg of the default run")
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="profiling runs: only the timed regions, the roofline pass and the HBM leg (no parity-mode / "
+                         "per-module / training / config-4 legs, whose launches of other sizes would mix into kernel statistics)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the multi-GPU code path (process group, bucketed all-gather) with one rank")
     ap.add_argument("--master-port", type=int, default=29533, help="rendezvous port of the self-launched N > 1 run")
@@ -549,19 +552,19 @@ def main():
         roof = agg = mfma_kernels = train = parity = modules = c4 = None
         if rank == 0:
             roof, mfma_kernels = roofline_leg(block, f, args.config, twin, N, min(args.steps, 50))
-            agg = agg_hbm_leg(dev)
-            if world == 1:
+            agg = agg_hbm_leg(dev)         # (its two kernels run in no forward at N = 11: they cannot mix into its statistics)
+            if world == 1 and not args.no_side_legs:
                 parity = parity_mode_leg(block, f, Bl, N)
                 modules = per_module_leg(block, f)
             G.set_noise_mode("host")
             # ---- one training step (fwd + loss + bwd + SGD) replayed from one hipGraph ------
             try:
                 train = (train_step_leg(N, Bl, SCALES, dev)
-                         if (world == 1 and not args.no_train_leg and not twin) else None)
+                         if (world == 1 and not args.no_train_leg and not args.no_side_legs and not twin) else None)
             except Exception as e:      # the headline forward numbers stand on their own
                 train = dict(error=f"{type(e).__name__}: {e}")
             # ---- BASELINE config 4 beside the metric's configuration (a short leg: driver-observed, not the headline) ----
-            if world == 1 and args.config == "c2" and not args.no_c4_leg:
+            if world == 1 and args.config == "c2" and not args.no_c4_leg and not args.no_side_legs:
                 try:
                     c4 = c4_leg(dev)
                 except Exception as e:

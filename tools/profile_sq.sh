@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 CFG=${1:-c2}
 OUT=gpurun_out/sq_$CFG
 rm -rf $OUT && mkdir -p $OUT
-COMMON="--config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-train-leg --no-c4-leg --streams 1"
+COMMON="--config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-side-legs --streams 1"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/p1 -- python3 bench.py $COMMON > /dev/null 2> $OUT/p1.err
 python3 - <<PY
 import csv, glob, collections, re
