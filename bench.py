@@ -503,10 +503,17 @@ def main():
         else:
             streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
             # every rank and every stream draws its own noise (a shard is not a copy of another shard)
-            graphs = [GraphedMultiScale(block, Bl, N, seed=99 + i + 1000 * rank, dtype=tdt) for i in range(S)]
+            # graphs replayed side by side on S > 1 streams: the throughput form (affinity + top-k as its own small launch,
+            # which fits beside the other streams' kernels); one stream: the latency form (it rides in the node stage)
+            graphs = [GraphedMultiScale(block, Bl, N, seed=99 + i + 1000 * rank, dtype=tdt, affinity_tail=(S == 1))
+                      for i in range(S)]
             for gr in graphs:
                 gr.f_in.copy_(f)
             runs = [(lambda gr=gr: gr()[0]) for gr in graphs]
+            # the single-stream figure (a caller with a dependency between steps) uses the latency form
+            lat_graph = graphs[0] if S == 1 else GraphedMultiScale(block, Bl, N, seed=99 + 1000 * rank, dtype=tdt,
+                                                                   affinity_tail=True)
+            lat_graph.f_in.copy_(f)
         torch.cuda.synchronize()
         step_no = [0]
 
@@ -541,7 +548,10 @@ def main():
         # ---- the same K steps on ONE stream, back to back (what a caller with a dependency between steps sees) ----
         def step1():
             with torch.cuda.stream(streams[0]):
-                runs[0]()
+                if args.no_graph:
+                    runs[0]()
+                else:
+                    lat_graph()
         single = None
         if not distributed:
             for _ in range(min(args.warmup, 10)):
@@ -593,6 +603,8 @@ def main():
                                    + ("bf16 storage / fp32 accumulate (the *_bf16 twins of every stage), " if twin else
                                       f"fp32 in and out (matrix stages: {matrix_path(False)[2]} — {matrix_path(False)[0]}), ")
                                    + f"device Philox noise, {'eager' if args.no_graph else f'hipGraph replay on {S} alternating streams'}"
+                                   + ("" if args.no_graph or S == 1 else " (5 + 1 launches per forward: affinity + top-k as its own "
+                                      "launch; value_single_stream: one stream, 5 launches, affinity + top-k in the node stage's tail)")
                                    + (f", + RCCL all-gather of the (B,N,{block.out_features}) embeddings, one call per {S} "
                                       f"steps, overlapped on a side stream" if distributed else ""),
                        "global_batch": B_total, "agents": N, "scales": SCALES,

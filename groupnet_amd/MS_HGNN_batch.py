@@ -561,7 +561,7 @@ def _pair_form() -> bool:
 
 
 def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor], Hs: Sequence[Optional[Tensor]],
-                        noises: Sequence, outs: Sequence[Optional[Tensor]], traces=None, join=None
+                        noises: Sequence, outs: Sequence[Optional[Tensor]], traces=None, join=None, affinity=None
                         ) -> List[Tuple[Tensor, Tensor]]:
     """The message-passing rounds of SEVERAL modules over the same scenes, stage by stage, each stage
     ONE grouped launch (model/MS_HGNN_batch.py:174-195 and :425-441 for every module at once).
@@ -573,7 +573,9 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
     `traces` (training): one `backward.ModuleTrace` per module, which receives the node features entering
     every round and the dist every round sampled — all the backward needs besides the inputs.
     `join`: called once after the first node stage has been launched and before anything reads Hs (a caller that
-    builds the incidences on a forked stream joins it here)."""
+    builds the incidences on a forked stream joins it here).
+    `affinity`: an `ops.AffinityTail` — the deferred affinity + top-k launch that produces Hs; it rides in the first
+    node-stage launch (its tail workgroups), or is issued beside it when that launch cannot take it."""
     n = len(mods)
     if not (n == len(hs) == len(Hs) == len(noises) == len(outs)) or n == 0:
         raise ValueError("run_message_passing: one h, H, noise and out per module")
@@ -609,7 +611,8 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
         # same launch (fp32 path; the bf16 twin runs both layers per pair on the matrix cores instead)
         specs = [((m.edge_aggregation_list[idx]._packed(), m.edge_aggregation_list[idx].edge_types)
                   if (sy and not twin and _pair_form()) else None) for m, sy in zip(mods, syms)]
-        xpq, As = ops.node_stage_grouped([(x, pk) for x, pk in zip(xs, pks)], keep, specs)
+        xpq, As = ops.node_stage_grouped([(x, pk) for x, pk in zip(xs, pks)], keep, specs,
+                                         affinity if idx == 0 else None)
         pair_A[:] = As
         if join is not None and idx == 0:
             join()       # the incidences were built on a forked stream beside the node stage (graph capture)

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -65,6 +65,11 @@ class BlockExtras(ctypes.Structure):    # gn_block_extras_t
                 ("x_raw", _P), ("x_dim", _I), ("M", _P), ("c", _P), ("f_contig", _P)]
 
 
+class AffinityJob(ctypes.Structure):   # gn_affinity_job_t
+    _fields_ = [("f", _P), ("corr", _P), ("H_list", ctypes.POINTER(_P)), ("k_list", ctypes.POINTER(_I)), ("n_scales", _I),
+                ("B", _I), ("N", _I), ("D", _I), ("extras", ctypes.POINTER(BlockExtras))]
+
+
 class PackSeg(ctypes.Structure):       # gn_pack_seg_t
     _fields_ = [("src", _P), ("dst", _P), ("ld", _I), ("rows", _I), ("cols", _I), ("place_r", _I), ("place_c", _I),
                 ("IT", _I), ("scale", _F), ("dst_ld", _I)]
@@ -111,6 +116,9 @@ SIGNATURES = {
     "gn_pack_segments_f32": (_I, [_P, _I, _I, _P]),
     "gn_node_mlp_f32": (_I, [ctypes.POINTER(NodeGroup), _I, _I, _P]),
     "gn_node_mlp_bf16": (_I, [ctypes.POINTER(NodeGroup), _I, _I, _P]),
+    "gn_node_mlp_affinity_f32": (_I, [ctypes.POINTER(NodeGroup), _I, _I, ctypes.POINTER(AffinityJob), _P]),
+    "gn_node_mlp_affinity_bf16": (_I, [ctypes.POINTER(NodeGroup), _I, _I, ctypes.POINTER(AffinityJob), _P]),
+    "gn_affinity_tail_lds_limit": (_SZ, []),
     "gn_node2edge_f32": (_I, [ctypes.POINTER(N2EGroup), _I, _I, _I, _P]),
     "gn_node2edge_bf16": (_I, [ctypes.POINTER(N2EGroup), _I, _I, _I, _P]),
     "gn_edge_mlp_gumbel_f32": (_I, [ctypes.POINTER(EdgeGroup), _I, _F, _U64, _P, _P]),

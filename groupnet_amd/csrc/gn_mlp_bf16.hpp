@@ -39,6 +39,7 @@
 // P = 1: 16 MFMAs).
 #pragma once
 #include "gn_mlp_common.hpp"
+#include "gn_affinity.hpp"
 
 #ifdef GN_STAMPS
 // Diagnostic build only (never the product): per-wave cycle stamps, read back with gn_debug_read_stamps.
@@ -489,6 +490,13 @@ struct NodeTable {
   int a_first[GN_MAX_GROUPS + 1];   // prefix of A workgroups per group, relative to chain_wgs
   int n, rows, wgs_per_group, chain_wgs;
   XcdSections xs;                   // sections: every group's chain, then every (group, output-tile chunk) of WA
+  // optional tail of the launch: blocks node_grid .. node_grid + aff_scenes - 1 each build the affinity / incidences of
+  // one scene (gn_affinity.hpp) — independent of the node stage, dispatched behind it
+  int node_grid, aff_scenes, aff_N, aff_D;
+  const void* aff_f;
+  float* aff_corr;
+  ScaleList aff_sl;
+  gn_block_extras_t aff_ex;
 };
 // output tiles of WA per "A" workgroup (a multiple of 4).  4: 264 workgroups of 16 sub-steps at B = 512 instead of 132 of
 // 32 — the A workgroups were the node stage's last to finish (same-session A/B: launch 22.1 -> 19.9 us).
@@ -600,6 +608,12 @@ constexpr int kRingF4For = WStream<P == 2 ? 3 : P>::kRingF4;
 template <int P, typename T>
 __global__ __launch_bounds__(256, 2) void node_stage_kernel(NodeTable Tb) {
   __shared__ f32x4 wring[kRingF4For<P>];
+  if (Tb.aff_scenes > 0 && (int)blockIdx.x >= Tb.node_grid) {       // (block-uniform)
+    extern __shared__ __align__(16) float aff_lds[];
+    affinity_topk_body<T>(reinterpret_cast<const T*>(Tb.aff_f), Tb.aff_corr, Tb.aff_sl, Tb.aff_N, Tb.aff_D, Tb.aff_ex,
+                          (int)blockIdx.x - Tb.node_grid, aff_lds);
+    return;
+  }
   run_with_fallback<P>([&](auto pc, ovf_t& ovf) { node_stage_body<decltype(pc)::value, T>(Tb, wring, ovf); });
 }
 

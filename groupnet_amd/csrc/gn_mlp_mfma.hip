@@ -875,8 +875,12 @@ static int x_mode(const G* groups, int n, F has) {
 }
 
 // ---- node stage ----------------------------------------------------------------------------------------------
+// largest LDS a scene of the fused affinity tail may ask for: beside the node stage's 36 KiB weight ring two workgroups
+// per CU must still fit
+constexpr size_t kAffTailLds = 24 * 1024;
 template <int P, typename T>
-static int node_stage_launch(const gn_node_group_t* groups, int n_groups, int rows, hipStream_t s) {
+static int node_stage_launch(const gn_node_group_t* groups, int n_groups, int rows, hipStream_t s,
+                             const gn_affinity_job_t* job = nullptr) {
   NodeTable Tb{};
   Tb.n = n_groups;
   Tb.rows = rows;
@@ -905,7 +909,35 @@ static int node_stage_launch(const gn_node_group_t* groups, int n_groups, int ro
   const int n_sec = (Tb.chain_wgs + a_wgs) / Tb.wgs_per_group;
   Tb.xs.n = n_sec <= GN_MAX_SECTIONS ? n_sec : 1;
   for (int i = 0; i <= Tb.xs.n; ++i) Tb.xs.first[i] = n_sec <= GN_MAX_SECTIONS ? i * Tb.wgs_per_group : i * (Tb.chain_wgs + a_wgs);
-  hipLaunchKernelGGL((node_stage_kernel<P, T>), dim3(gn_xcd_grid(Tb.xs)), dim3(256), 0, s, Tb);
+  const int node_grid = gn_xcd_grid(Tb.xs);
+  size_t aff_lds = 0;
+  if (job != nullptr) {
+    // the affinity + top-k of job->B scenes as the launch's tail workgroups (same checks as gn_affinity_topk_*)
+    const bool embed = job->extras != nullptr && job->extras->x_raw != nullptr;
+    if (embed && sizeof(T) != sizeof(float)) return GN_ERR_SHAPE;
+    if (!embed) GN_CHECK(need(job->f, true));
+    if (job->B <= 0 || job->N <= 0 || job->D <= 0 || (job->D & 3) || job->D > 1024) return GN_ERR_SHAPE;
+    GN_CHECK(fill_scales(Tb.aff_sl, job->H_list, job->k_list, job->n_scales, job->N));
+    if (embed) {
+      if (job->extras->x_dim <= 0 || !job->extras->M || !job->extras->c || !job->extras->f_contig) return GN_ERR_NULL;
+      if (!gn_aligned16(job->extras->c) || !gn_aligned16(job->extras->f_contig)) return GN_ERR_ALIGN;
+    }
+    aff_lds = affinity_fused_lds(job->N, job->D, embed ? job->extras->x_dim : 0);
+    if (aff_lds > kAffTailLds) return GN_ERR_LDS;
+    if (job->extras != nullptr) {
+      Tb.aff_ex = *job->extras;
+      if (Tb.aff_ex.f_out != nullptr && (!gn_aligned16(Tb.aff_ex.f_out) || Tb.aff_ex.f_out_ld < job->D || (Tb.aff_ex.f_out_ld & 3)))
+        return GN_ERR_ALIGN;
+      Tb.aff_sl.H_cat = Tb.aff_ex.H_cat;
+    }
+    Tb.node_grid = node_grid;
+    Tb.aff_scenes = job->B;
+    Tb.aff_N = job->N;
+    Tb.aff_D = job->D;
+    Tb.aff_f = job->f;
+    Tb.aff_corr = job->corr;
+  }
+  hipLaunchKernelGGL((node_stage_kernel<P, T>), dim3(node_grid + Tb.aff_scenes), dim3(256), aff_lds, s, Tb);
   return gn_check_launch();
 }
 
@@ -943,6 +975,26 @@ extern "C" int gn_node_mlp_bf16(const gn_node_group_t* groups, int n_groups, int
   if (rows <= 0) return GN_ERR_SHAPE;
   return node_stage_launch<1, __bf16>(groups, n_groups, rows, (hipStream_t)stream);
 }
+
+// The node stage with the fused affinity + top-k launch as its tail workgroups (bf16-/fp16-core kernels only: every group
+// must carry its `Wx` image).
+extern "C" int gn_node_mlp_affinity_f32(const gn_node_group_t* groups, int n_groups, int rows, const gn_affinity_job_t* job,
+                                        gn_stream_t stream) {
+  GN_CHECK(check_groups(groups, n_groups));
+  if (rows <= 0 || job == nullptr) return GN_ERR_SHAPE;
+  if (x_mode(groups, n_groups, [](const gn_node_group_t& G) { return G.Wx != nullptr; }) != 1) return GN_ERR_SHAPE;
+  const int hm = x_mode(groups, n_groups, [](const gn_node_group_t& G) { return G.Wh != nullptr; });
+  if (hm < 0) return GN_ERR_SHAPE;
+  return hm ? node_stage_launch<2, float>(groups, n_groups, rows, (hipStream_t)stream, job)
+            : node_stage_launch<3, float>(groups, n_groups, rows, (hipStream_t)stream, job);
+}
+extern "C" int gn_node_mlp_affinity_bf16(const gn_node_group_t* groups, int n_groups, int rows, const gn_affinity_job_t* job,
+                                         gn_stream_t stream) {
+  GN_CHECK(check_groups(groups, n_groups));
+  if (rows <= 0 || job == nullptr) return GN_ERR_SHAPE;
+  return node_stage_launch<1, __bf16>(groups, n_groups, rows, (hipStream_t)stream, job);
+}
+extern "C" size_t gn_affinity_tail_lds_limit(void) { return kAffTailLds; }
 
 // Row-block pairs from which the bf16-storage edge / aggregation launches run two row blocks per wave (the chip must
 // still be filled: >= 2048 waves).  GN_RB2_MIN_PAIRS is a TEST knob: the parity suite lowers it so that the launcher's

@@ -31,7 +31,10 @@ class GraphedMultiScale:
     """
 
     def __init__(self, block: MultiScaleHGNN, B: int, N: int, seed: int = 0, device: Optional[torch.device] = None,
-                 warmup: int = 2, dtype: torch.dtype = torch.float32):
+                 warmup: int = 2, dtype: torch.dtype = torch.float32, affinity_tail: Optional[bool] = None):
+        """``affinity_tail``: capture with `block.affinity_tail` set to this value (None: as the block has it) — True =
+        the latency form (affinity + top-k in the first node stage's tail), False = the throughput form for graphs that
+        are replayed side by side on several streams (see `MultiScaleHGNN.affinity_tail`)."""
         p = next(block.parameters())
         self.device = device or p.device
         if self.device.type != "cuda":
@@ -44,6 +47,9 @@ class GraphedMultiScale:
         self.draws_per_step = sum(b * e * k for (b, e, k) in block.noise_shapes(B, N)) * block.interaction.nmp_layers
         self.graph = torch.cuda.CUDAGraph()
         prev = (_mods._NoiseState.mode, _mods._NoiseState.seed, _mods._NoiseState.offset, _mods._NoiseState.counter)
+        prev_tail = block.affinity_tail
+        if affinity_tail is not None:
+            block.affinity_tail = bool(affinity_tail)
         try:
             with torch.no_grad(), torch.cuda.device(self.device):
                 side = torch.cuda.Stream(device=self.device)
@@ -58,6 +64,7 @@ class GraphedMultiScale:
                 with torch.cuda.graph(self.graph):
                     self.out, self.H = self._step()
         finally:
+            block.affinity_tail = prev_tail
             _mods.set_noise_mode(prev[0], prev[1], prev[2], prev[3])
 
     def _step(self) -> Tuple[Tensor, Optional[Tensor]]:

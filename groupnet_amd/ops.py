@@ -64,6 +64,10 @@ BF16X6 = os.environ.get("GN_BF16X6", "1") != "0"   # fp32 entry points: fp32-acc
 F16X3 = BF16X6 and os.environ.get("GN_PRECISION", "f16x3").lower() != "bf16x6"
 
 
+# the fused affinity + top-k launch as the tail workgroups of the first node stage (GN_AFFINITY_TAIL = 0: its own launch)
+_AFFINITY_TAIL = os.environ.get("GN_AFFINITY_TAIL", "1") != "0"
+
+
 def precision() -> str:
     """Matrix path of the fp32 entry points: 'f16x3' (default), 'bf16x6' or 'fp32' (the fp32 matrix cores)."""
     return "f16x3" if (BF16X6 and F16X3) else ("bf16x6" if BF16X6 else "fp32")
@@ -277,6 +281,54 @@ def affinity_topk(f: Optional[Tensor], scales: Sequence[int], want_corr: bool = 
     if embed is not None:
         return corr, Hs, H_cat, f_contig
     return corr, Hs, H_cat
+
+
+class AffinityTail:
+    """The fused affinity + top-k launch of a forward, DEFERRED: outputs are allocated now, the work is issued as the tail
+    workgroups of the first node-stage launch (`node_stage_grouped(..., affinity=job)` -> gn_node_mlp_affinity_*), or —
+    when nothing picks it up — by `launch()` as the stand-alone launch.  Same arguments as `affinity_topk` (without the
+    embedding front-end)."""
+
+    def __init__(self, f: Tensor, scales: Sequence[int], want_corr: bool = False, f_out: Optional[Tensor] = None,
+                 want_H_cat: bool = False, counter: Optional[Tensor] = None, counter_add: int = 0):
+        _req(f, "f", (None, None, None), _ACT_DTYPES)
+        self.f, self.scales = f, [int(s) for s in scales]
+        B, N, D = f.shape
+        self.corr = torch.empty((B, N, N), dtype=torch.float32, device=f.device) if want_corr else None
+        self.Hs = _alloc_incidence(B, N, self.scales, f.device)
+        self._Hl, self._kl, n = _scale_args(self.Hs, self.scales)
+        self._ex = _lib.BlockExtras()
+        self.H_cat = None
+        if f_out is not None:
+            if not (f_out.is_cuda and f_out.dtype == f.dtype and tuple(f_out.shape) == (B, N, D)
+                    and f_out.stride(2) == 1 and f_out.stride(0) == N * f_out.stride(1)):
+                raise ValueError("f_out: a (B,N,D) last-dim slice of a contiguous GPU tensor of f's dtype")
+            self._ex.f_out, self._ex.f_out_ld = f_out.data_ptr(), f_out.stride(1)
+        if want_H_cat:
+            self.H_cat = torch.empty((B, sum(h.shape[1] for h in self.Hs), N), dtype=f.dtype, device=f.device)
+            self._ex.H_cat = self.H_cat.data_ptr()
+        if counter is not None:
+            if not (counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1):
+                raise ValueError("counter: a 1-element int64 GPU tensor")
+            self._ex.counter, self._ex.counter_add = counter.data_ptr(), int(counter_add) & (2**64 - 1)
+        self._keep = (f_out, counter)
+        self.job = _lib.AffinityJob(f.data_ptr(), 0 if self.corr is None else self.corr.data_ptr(), self._Hl, self._kl, n,
+                                    B, N, D, ctypes.pointer(self._ex))
+        self.done = False
+
+    def fits_tail(self) -> bool:
+        B, N, D = self.f.shape
+        return N * (D + 4) * 4 + 8 + N * N * 8 <= load().gn_affinity_tail_lds_limit()
+
+    def launch(self) -> None:
+        """The stand-alone launch (nothing took the job along)."""
+        if self.done:
+            return
+        B, N, D = self.f.shape
+        with torch.cuda.device(self.f.device):
+            check(_fn("gn_affinity_topk", self.f.dtype)(_ptr(self.f), _ptr(self.corr), self._Hl, self._kl, len(self.Hs), B, N, D,
+                                                        ctypes.byref(self._ex), stream_handle()), "gn_affinity_topk")
+        self.done = True
 
 
 # ---- weight packing ------------------------------------------------------------------------------
@@ -517,7 +569,8 @@ def _groups(n: int) -> None:
 
 
 def node_stage_grouped(items: Sequence[Tuple[Tensor, dict]], keep: Optional[List[dict]] = None,
-                       a_specs: Optional[Sequence[Optional[Tuple[dict, int]]]] = None
+                       a_specs: Optional[Sequence[Optional[Tuple[dict, int]]]] = None,
+                       affinity: Optional["AffinityTail"] = None
                        ) -> Tuple[List[Tuple[Tensor, Tensor]], List[Optional[Tensor]]]:
     """One launch for the node rows of several modules: items = [(x (B,N,64), pk{"W","bias","xi"})] with equal
     shapes -> [(x', pq)].  ``keep`` (training) receives per group {"hid": relu(W0 x + b0) (rows, 256)}.
@@ -560,8 +613,19 @@ def node_stage_grouped(items: Sequence[Tuple[Tensor, dict]], keep: Optional[List
                                 hid_ptr, wx, *a_fields, _himg(pk, "chain", dt) if wx else 0, wah)
         outs.append((xp, pq))
     flops = sum(rows * 2 * (64 * 256 + 256 * 64 + 64 * 64 + (64 * 128 * int(a.KA) if a.A else 0)) for a in arr)
+    # ``affinity``: a deferred fused affinity + top-k launch rides as this launch's tail workgroups (bf16-/fp16-core
+    # kernels, a scene tile within the tail's LDS limit); otherwise it is issued on its own right here
+    ride = (affinity is not None and not affinity.done and all(bool(a.Wx) for a in arr) and affinity.fits_tail()
+            and affinity.f.dtype == dt and affinity.f.device == x0.device and _AFFINITY_TAIL)
+    if affinity is not None and not ride:
+        affinity.launch()
     with torch.cuda.device(x0.device), _Probed("node_stage_kernel", flops):
-        check(_fn("gn_node_mlp", dt)(arr, len(items), rows, stream_handle()), "gn_node_mlp")
+        if ride:
+            check(_fn("gn_node_mlp_affinity", dt)(arr, len(items), rows, ctypes.byref(affinity.job), stream_handle()),
+                  "gn_node_mlp_affinity")
+            affinity.done = True
+        else:
+            check(_fn("gn_node_mlp", dt)(arr, len(items), rows, stream_handle()), "gn_node_mlp")
     for g, x, apk, K in late:
         As[g] = node_linear(x, apk["W1cat"], apk["b1half"], K * 128)
     return outs, As

@@ -199,6 +199,27 @@ typedef struct {
 } gn_node_group_t;
 int gn_node_mlp_f32(const gn_node_group_t* groups, int n_groups, int rows, gn_stream_t stream);
 int gn_node_mlp_bf16(const gn_node_group_t* groups, int n_groups, int rows, gn_stream_t stream);
+/* The node stage of a forward's FIRST round needs only the agent features, not the incidences: A0 + A1 of the same
+ * forward (gn_affinity_topk_*: model/GroupNet_nba.py:284-286, model/MS_HGNN_batch.py:372-388) can ride in the same
+ * launch.  `job` = the arguments of gn_affinity_topk_* (f may be NULL with the embedding front-end in `extras`); its B
+ * scenes become the launch's TAIL workgroups, dispatched behind the node stage's own and filling the CUs its short
+ * workgroups leave early — one launch and one launch boundary fewer (measured at B = 512, N = 11: 7.3 us + 1.3 us).
+ * Results are those of the two separate launches, bit for bit.  Needs the groups' bf16-core images (`Wx`) and a scene
+ * tile of at most gn_affinity_tail_lds_limit() bytes (N (D + 4 + x_dim) 4 + N N 8 + 8), else GN_ERR_SHAPE / GN_ERR_LDS. */
+typedef struct {
+  const void* f;             /* [T] (B, N, D) agent features, or NULL with extras->x_raw */
+  float* corr;               /* optional (B, N, N) */
+  float* const* H_list;      /* n_scales incidence outputs, as gn_affinity_topk_f32 */
+  const int* k_list;
+  int n_scales;
+  int B, N, D;
+  const gn_block_extras_t* extras;   /* optional */
+} gn_affinity_job_t;
+int gn_node_mlp_affinity_f32(const gn_node_group_t* groups, int n_groups, int rows, const gn_affinity_job_t* job,
+                             gn_stream_t stream);
+int gn_node_mlp_affinity_bf16(const gn_node_group_t* groups, int n_groups, int rows, const gn_affinity_job_t* job,
+                              gn_stream_t stream);
+size_t gn_affinity_tail_lds_limit(void);
 
 /* ---- A3 (second half): attention-weighted node -> edge pooling ---------------------------
  * Replaces the rest of node2edge, MS_HGNN_batch.py:127-141 / 359-370:

@@ -1347,3 +1347,40 @@ def test_pair_scatter_read_once_is_bit_identical(N, dtype, monkeypatch):
                     want[:, j] += feat[:, p]
         assert float((got[..., :64] - want / N).abs().max()) <= 1e-5
         assert float((got[..., 64:] - ori / N).abs().max()) <= 1e-6 * float(ori.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,scales", [(37, 11, [2, 5, 11]), (512, 11, [2, 5, 11]), (3, 30, [4, 30])])
+def test_affinity_tail_of_the_node_stage_is_bit_identical(B, N, scales, dtype):
+    """The fused affinity + top-k launch riding as the tail workgroups of the first node-stage launch
+    (gn_node_mlp_affinity_*, the block's default) against the two separate launches (`ops._AFFINITY_TAIL = False`):
+    same code for a scene either way — features, incidence and the f copy identical, and the launch really is gone
+    (the block issues one launch fewer)."""
+    from groupnet_amd import ops
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    torch.manual_seed(5)
+    blk = MultiScaleHGNN(scales).to(dev()).eval()
+    f = torch.randn(B, N, 64, device=dev()).to(dtype)
+    noise = [[torch.rand(s, device=dev())] for s in blk.noise_shapes(B, N)]
+    counts = {}
+    orig = ops.AffinityTail.launch
+
+    def counting(self):
+        counts["alone"] = counts.get("alone", 0) + (0 if self.done else 1)
+        return orig(self)
+    ops.AffinityTail.launch = counting
+    try:
+        with torch.no_grad():
+            a, Ha = blk(f, noise_u=noise)
+            a, Ha = a.clone(), Ha.clone()
+            rode = counts.get("alone", 0) == 0
+            ops._AFFINITY_TAIL = False
+            try:
+                b, Hb = blk(f, noise_u=noise)
+            finally:
+                ops._AFFINITY_TAIL = True
+    finally:
+        ops.AffinityTail.launch = orig
+    assert rode and counts.get("alone", 0) == 1          # first call rode in the node stage, second was its own launch
+    assert torch.equal(a, b) and torch.equal(Ha, Hb)
+    assert torch.equal(a[..., :64], f)
