@@ -1384,3 +1384,29 @@ def test_affinity_tail_of_the_node_stage_is_bit_identical(B, N, scales, dtype):
     assert rode and counts.get("alone", 0) == 1          # first call rode in the node stage, second was its own launch
     assert torch.equal(a, b) and torch.equal(Ha, Hb)
     assert torch.equal(a[..., :64], f)
+
+
+@pytest.mark.parametrize("knob", ["GN_XCD", "GN_AGG_HSTAGE", "GN_AGG_LINES"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_order_and_gather_knobs_are_bit_identical(knob, dtype, monkeypatch):
+    """Knobs that change WHERE work runs or where operands are read from, never what is computed: GN_XCD=0 (workgroups in
+    dispatch order instead of the XCD-aware permutation), GN_AGG_HSTAGE=0 (hyper gather of the typed aggregation from L2
+    in line layout instead of LDS-staged rows), GN_AGG_LINES=0 (per-lane gather).  The library reads them at every
+    launch (a `static` getenv froze the first value and made such A/B tests vacuous), so the two settings
+    run different code; outputs must be identical bit for bit.  B = 512 so that the XCD order is active (>= 64
+    workgroups) and the hyper groups run two waves per row block."""
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    torch.manual_seed(13)
+    B, N, scales = 512, 11, [2, 5, 11]
+    blk = MultiScaleHGNN(scales).to(dev()).eval()
+    f = torch.randn(B, N, 64, device=dev()).to(dtype)
+    U = [[torch.rand(s, device=dev())] for s in blk.noise_shapes(B, N)]
+    outs = {}
+    with torch.no_grad():
+        for v in ("1", "0"):
+            monkeypatch.setenv(knob, v)
+            if knob == "GN_AGG_LINES":
+                monkeypatch.setenv("GN_AGG_HSTAGE", "0")      # (the line layout is what runs without the stage)
+            a, H = blk(f, noise_u=U)
+            outs[v] = (a.clone(), H.clone())
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
