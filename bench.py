@@ -492,7 +492,10 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     f = torch.randn(Bl, N, 64, generator=g, device=dev).to(tdt)     # synthetic agent embeddings, resident in HBM
     S = 1 if args.no_graph else max(1, args.streams)
-    bg = sharding.BucketedGather(S, (Bl, N, block.out_features), dev, dtype=tdt) if distributed else None
+    # what crosses xGMI: the output embeddings = the COMPUTED columns (Bl, N, 64 (1 + scales)) of the feature tensor
+    # (SURVEY 8e); its first 64 columns are a copy of the rank's own input, which no rank needs back
+    gather_cols = block.out_features - block.h_dim
+    bg = sharding.BucketedGather(S, (Bl, N, gather_cols), dev, dtype=tdt) if distributed else None
 
     with torch.no_grad():
         if args.no_graph:
@@ -523,7 +526,7 @@ def main():
             with torch.cuda.stream(streams[i]):
                 out = runs[i]()
                 if bg is not None:
-                    bg.put(out)
+                    bg.put(out[..., block.h_dim:])
             return out
 
         def fence():
@@ -605,7 +608,8 @@ def main():
                                    + f"device Philox noise, {'eager' if args.no_graph else f'hipGraph replay on {S} alternating streams'}"
                                    + ("" if args.no_graph or S == 1 else " (5 + 1 launches per forward: affinity + top-k as its own "
                                       "launch; value_single_stream: one stream, 5 launches, affinity + top-k in the node stage's tail)")
-                                   + (f", + RCCL all-gather of the (B,N,{block.out_features}) embeddings, one call per {S} "
+                                   + (f", + RCCL all-gather of the (B,N,{block.out_features - block.h_dim}) output embeddings (the computed "
+                                      f"columns of the (B,N,{block.out_features}) feature tensor; the rest is the rank's input), one call per {S} "
                                       f"steps, overlapped on a side stream" if distributed else ""),
                        "global_batch": B_total, "agents": N, "scales": SCALES,
                        "parallelism": f"batch-sharded x{world}"},

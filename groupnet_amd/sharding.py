@@ -4,7 +4,8 @@ Scenes are independent (batch dim leads every tensor, weights are shared, no Bat
 SURVEY.md §8e), so rank r owns the contiguous scene range ``shard_range(B, r, R)``, runs the
 block on it with replicated weights and no data-path collective, and ONE all-gather (RCCL over
 xGMI through ``torch.distributed``; backend "nccl" is RCCL on ROCm) returns the concatenated
-output embeddings ``(B, N, 64*(2+S))`` to every rank.  The reference has no distributed code at
+output embeddings — the computed columns ``(B, N, 64*(1+S))`` of the ``(B, N, 64*(2+S))`` feature tensor, whose first
+64 columns are a copy of the input every rank already holds — to every rank.  The reference has no distributed code at
 all; this is new design.
 
 Noise under sharding: to stay identical to a single-device run, a rank must use the rows it owns
@@ -113,7 +114,8 @@ def default_shard_noise(block, B: int, N: int, start: int, stop: int, device) ->
 
 
 def sharded_forward(block: Callable[..., Tuple[Tensor, Optional[Tensor]]], f_full: Tensor,
-                    noise_full: Optional[Sequence] = None, group=None, gather_H: bool = False):
+                    noise_full: Optional[Sequence] = None, group=None, gather_H: bool = False,
+                    input_prefix: bool = True):
     """Run `block` on this rank's scenes of `f_full` (every rank holds the full input, as a
     data-parallel caller would after its own loader) and all-gather the features.
 
@@ -122,6 +124,10 @@ def sharded_forward(block: Callable[..., Tuple[Tensor, Optional[Tensor]]], f_ful
     ``noise_full`` = the full-batch uniforms (sliced here), or None: every rank then takes its rows of the
     full-batch default streams (`default_shard_noise`), so that the result equals a single-device run —
     never the same noise on different scene shards.
+    ``input_prefix``: the block's features start with a copy of its input (`final = cat(f, inter, hyper...)`,
+    model/GroupNet_nba.py:301-309).  Every rank already holds those columns for the whole batch (`f_full`), so only the
+    COMPUTED columns — the output embeddings, 64*(1+S) of the 64*(2+S) — cross xGMI (5.8 MB instead of 7.2 MB
+    per 512 scenes) and the result is assembled as cat(f_full, gathered).  False gathers the whole tensor.
     Returns `(features_full (B, N, F), H_full or local H)`.
     """
     world = dist.get_world_size(group)
@@ -136,7 +142,11 @@ def sharded_forward(block: Callable[..., Tuple[Tensor, Optional[Tensor]]], f_ful
     else:
         noise_local = None
     feats, H = block(f_local, noise_u=noise_local)
-    feats_full = all_gather_rows(feats, B, group)
+    D = f_full.shape[-1]
+    if input_prefix and feats.shape[-1] > D and feats.dtype == f_full.dtype:
+        feats_full = torch.cat((f_full, all_gather_rows(feats[..., D:].contiguous(), B, group)), dim=-1)
+    else:
+        feats_full = all_gather_rows(feats, B, group)
     if gather_H and H is not None:
         H = all_gather_rows(H, B, group)
     return feats_full, H
