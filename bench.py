@@ -445,6 +445,8 @@ def main():
                          "per-module / training / config-4 legs, whose launches of other sizes would mix into kernel statistics)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the multi-GPU code path (process group, bucketed all-gather) with one rank")
+    ap.add_argument("--gather-full", action="store_true",
+                    help="N > 1: all-gather the whole (B,N,64(2+S)) feature tensor instead of its computed columns")
     ap.add_argument("--master-port", type=int, default=29533, help="rendezvous port of the self-launched N > 1 run")
     ap.add_argument("--dry-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the launch command (JSON) instead of running it")
@@ -494,7 +496,7 @@ def main():
     S = 1 if args.no_graph else max(1, args.streams)
     # what crosses xGMI: the output embeddings = the COMPUTED columns (Bl, N, 64 (1 + scales)) of the feature tensor
     # (SURVEY 8e); its first 64 columns are a copy of the rank's own input, which no rank needs back
-    gather_cols = block.out_features - block.h_dim
+    gather_cols = block.out_features if args.gather_full else block.out_features - block.h_dim
     bg = sharding.BucketedGather(S, (Bl, N, gather_cols), dev, dtype=tdt) if distributed else None
 
     with torch.no_grad():
@@ -514,9 +516,11 @@ def main():
                 gr.f_in.copy_(f)
             runs = [(lambda gr=gr: gr()[0]) for gr in graphs]
             # the single-stream figure (a caller with a dependency between steps) uses the latency form
-            lat_graph = graphs[0] if S == 1 else GraphedMultiScale(block, Bl, N, seed=99 + 1000 * rank, dtype=tdt,
-                                                                   affinity_tail=True)
-            lat_graph.f_in.copy_(f)
+            lat_graph = None
+            if not distributed:
+                lat_graph = graphs[0] if S == 1 else GraphedMultiScale(block, Bl, N, seed=99 + 1000 * rank, dtype=tdt,
+                                                                       affinity_tail=True)
+                lat_graph.f_in.copy_(f)
         torch.cuda.synchronize()
         step_no = [0]
 
@@ -526,7 +530,7 @@ def main():
             with torch.cuda.stream(streams[i]):
                 out = runs[i]()
                 if bg is not None:
-                    bg.put(out[..., block.h_dim:])
+                    bg.put(out if args.gather_full else out[..., block.h_dim:])
             return out
 
         def fence():

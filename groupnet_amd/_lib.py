@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -143,6 +143,7 @@ SIGNATURES = {
     "gn_node2edge_bwd_grouped_f32": (_I, [ctypes.POINTER(N2EBwdGroup), _I, _I, _I, _P]),
     "gn_philox_uniform_f32": (_I, [_P, _SZ, _U64, _U64, _P, _P]),
     "gn_counter_add_u64": (_I, [_P, _U64, _P]),
+    "gn_copy_2d": (_I, [_P, _SZ, _P, _SZ, _SZ, _I, _P]),
 }
 
 _lib = None

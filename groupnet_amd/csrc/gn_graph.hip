@@ -1052,7 +1052,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) 
 
 }  // namespace
 
-extern "C" int gn_abi_version(void) { return 31; }
+extern "C" int gn_abi_version(void) { return 32; }
 
 extern "C" const char* gn_strerror(int code) {
   switch (code) {
@@ -1412,6 +1412,34 @@ extern "C" int gn_agg_scatter_f32(const gn_scatter_group_t* groups, int n_groups
 extern "C" int gn_agg_scatter_bf16(const gn_scatter_group_t* groups, int n_groups, int B, int N, float divisor,
                                    gn_stream_t stream) {
   return scatter_launch<__bf16>(groups, n_groups, B, N, divisor, (hipStream_t)stream);
+}
+
+// Pitched copy (rows x width bytes, 16-byte pieces): the column block of the feature tensor that a rank ships into its
+// all-gather staging bank (sharding.BucketedGather) — a strided torch copy_ of the same 5.8 MB took ~3x as long.
+__global__ __launch_bounds__(kBlock) void copy_2d_kernel(const unsigned char* __restrict__ src, size_t spitch,
+                                                         unsigned char* __restrict__ dst, size_t dpitch, int w16,
+                                                         long long total) {
+  for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (long long)gridDim.x * kBlock) {
+    const long long r = idx / w16;
+    const int c = (int)(idx - r * w16);
+    *reinterpret_cast<f32x4*>(dst + r * dpitch + 16 * (size_t)c) = *reinterpret_cast<const f32x4*>(src + r * spitch + 16 * (size_t)c);
+  }
+}
+extern "C" int gn_copy_2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, int rows,
+                          gn_stream_t stream) {
+  GN_REQUIRE_PTR(dst);
+  GN_REQUIRE_PTR(src);
+  if (rows <= 0 || width_bytes == 0 || (width_bytes & 15) || (dst_pitch & 15) || (src_pitch & 15) || dst_pitch < width_bytes ||
+      src_pitch < width_bytes)
+    return GN_ERR_SHAPE;
+  GN_REQUIRE_ALIGNED(dst);
+  GN_REQUIRE_ALIGNED(src);
+  const int w16 = (int)(width_bytes / 16);
+  const long long total = (long long)rows * w16;
+  hipLaunchKernelGGL(copy_2d_kernel, dim3(capped_grid(total, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream,
+                     reinterpret_cast<const unsigned char*>(src), src_pitch, reinterpret_cast<unsigned char*>(dst), dst_pitch, w16,
+                     total);
+  return gn_check_launch();
 }
 
 __global__ void counter_add_kernel(unsigned long long* ctr, unsigned long long add) {

@@ -1094,3 +1094,21 @@ def counter_add(counter: Tensor, add: int) -> None:
         check(load().gn_counter_add_u64(_ptr(counter), int(add), stream_handle()), "gn_counter_add_u64")
 
 
+
+
+def copy_cols(dst: Tensor, src: Tensor) -> None:
+    """dst (contiguous) <- src, where src is a last-dim slice of a wider contiguous tensor (a column block of the
+    concatenated features): one pitched copy launch (`gn_copy_2d`) instead of a strided elementwise copy."""
+    if not (src.is_cuda and dst.is_cuda and src.dtype == dst.dtype and tuple(src.shape) == tuple(dst.shape)):
+        raise ValueError("copy_cols: GPU tensors of equal shape and dtype")
+    w = src.shape[-1] * src.element_size()
+    rows = src.numel() // src.shape[-1]
+    ok = (dst.is_contiguous() and src.stride(-1) == 1 and w % 16 == 0 and src.dim() >= 2
+          and (src.stride(-2) * src.element_size()) % 16 == 0 and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0
+          and all(src.stride(d) == src.stride(d + 1) * src.shape[d + 1] for d in range(src.dim() - 2)))
+    if not ok:
+        dst.copy_(src, non_blocking=True)
+        return
+    with torch.cuda.device(src.device):
+        check(load().gn_copy_2d(_P(dst.data_ptr()), w, _P(src.data_ptr()), src.stride(-2) * src.element_size(), w, rows,
+                                stream_handle()), "gn_copy_2d")

@@ -241,7 +241,11 @@ class BucketedGather:
             cur = torch.cuda.current_stream(self.device)
             if self.bank_free[bank] is not None:
                 cur.wait_event(self.bank_free[bank])
-            self.banks[bank, i].copy_(out, non_blocking=True)
+            if out.is_contiguous():
+                self.banks[bank, i].copy_(out, non_blocking=True)
+            else:
+                from . import ops            # (a column block of a wider tensor: one pitched copy launch)
+                ops.copy_cols(self.banks[bank, i], out)
             ev = torch.cuda.Event()
             ev.record(cur)
             self.ready[i] = ev

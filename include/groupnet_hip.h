@@ -67,6 +67,11 @@ typedef void* gn_stream_t; /* hipStream_t */
 #define GN_MAX_TYPES 16       /* edge types K <= 16 (reference: 6 pairwise, 10 hyper) */
 #define GN_MAX_SCALES 8
 
+/* Pitched device-to-device copy of `rows` rows of `width_bytes` (multiples of 16 bytes, 16-byte aligned): the column block of
+ * the concatenated feature tensor (model/GroupNet_nba.py:301-309) that a rank ships into its all-gather staging bank. */
+int gn_copy_2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, int rows,
+               gn_stream_t stream);
+
 /* ABI version of this header; bumped on any signature change. */
 int gn_abi_version(void);
 /* Short static description of a GN_ERR_* code. */

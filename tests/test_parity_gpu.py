@@ -1410,3 +1410,17 @@ def test_order_and_gather_knobs_are_bit_identical(knob, dtype, monkeypatch):
             a, H = blk(f, noise_u=U)
             outs[v] = (a.clone(), H.clone())
     assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_copy_cols_equals_torch_copy(dtype):
+    """ops.copy_cols (gn_copy_2d: the pitched copy that stages a rank's output columns for the all-gather) against
+    torch's strided copy, incl. the fallback for shapes the kernel does not take."""
+    from groupnet_amd import ops
+    torch.manual_seed(2)
+    full = torch.randn(37, 11, 320, device=dev()).to(dtype)
+    for lo, hi in ((64, 320), (0, 64), (8, 72), (3, 67)):          # the last one is not 16-byte aligned: torch fallback
+        src = full[..., lo:hi]
+        dst = torch.zeros(37, 11, hi - lo, device=dev(), dtype=dtype)
+        ops.copy_cols(dst, src)
+        assert torch.equal(dst, src.contiguous()), (lo, hi)

@@ -4,6 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final3
 rm -rf $O && mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; tail -1 $O/tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py --gpus 1 --steps 200 --warmup 20 > $O/bench_c2.json 2> $O/bench_c2.err && echo bench_c2 ok
 python bench.py --config c4 --steps 20 --warmup 5 > $O/bench_c4.json 2> $O/bench_c4.err && echo bench_c4 ok
 python bench.py --force-dist --steps 21 --warmup 5 --no-cpu-baseline --no-side-legs > $O/bench_fd.json 2> $O/bench_fd.err && echo bench_fd ok
