@@ -657,7 +657,8 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
                 # pairwise: eo = ori_i + ori_j makes the typed MLP's first layer linear in the two nodes, so
                 # it ran once per node (N rows instead of N(N+1)/2 pairs) in this round's node stage; the
                 # pair form does the rest
-                src = ops.PairSpec(pair_A[i])
+                src = ops.PairSpec(pair_A[i], node=(ops.node_form_enabled() and ops.BF16X6 and N <= ops.NODE_FORM_MAX_N
+                                                     and K <= ops.NODE_FORM_MAX_K and N <= _FUSED_SCATTER_MAX_N))
             elif syms[i]:
                 src = ops.GatherSpec(oris[i], None, True)     # bf16 twin: both layers per unordered pair
             elif N <= _FUSED_GATHER_MAX_N:
@@ -667,8 +668,10 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
             items.append((src, edge_feats[i], pk, K))
         feats = ops.agg_mlp_grouped(items)
         if N <= _FUSED_SCATTER_MAX_N:
-            # cat(H^T feat, ori) / N is formed inside the MLP kernel that consumes it
-            return [ops.ScatterSpec(f, H, o, sy) for f, H, o, sy in zip(feats, Hs, oris, syms)]
+            # cat(H^T feat, ori) / N is formed inside the MLP kernel that consumes it (node form: H^T feat is what the
+            # aggregation kernel wrote)
+            return [ops.NodeAggSpec(f, o) if (isinstance(it[0], ops.PairSpec) and it[0].node) else ops.ScatterSpec(f, H, o, sy)
+                    for f, H, o, sy, it in zip(feats, Hs, oris, syms, items)]
         return ops.agg_scatter_grouped([(f, H, o, sy) for f, H, o, sy in zip(feats, Hs, oris, syms)])
 
     res = edge_mlp([m.nmp_mlp_start for m in mods], node2edge(hs, 0), True)

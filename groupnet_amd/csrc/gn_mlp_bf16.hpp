@@ -780,6 +780,284 @@ __device__ __forceinline__ void add_b2(const float* __restrict__ b2k, float efk,
 }
 
 constexpr int kAggPartBytes = 4 * 32 * (64 + 8) * 4;
+
+// ---- node form of the pairwise typed aggregation (gn_agg_group_t.node_form; N <= 16, K <= 12) ----------------------------
+// edge_aggregation.forward consumes the per-edge feature only through H^T feat (MS_HGNN_batch.py:267), and the type
+// weighting and layer 2 are linear, so they commute with that sum:
+//   (H^T feat)[n] = sum_k W2k S[n,k] + sum_k b2k c[n,k],   S[n,k] = sum_j ef[p(n,j),k] relu(A[n,k] + A[j,k]),
+//                                                          c[n,k] = sum_j ef[p(n,j),k]
+// (ef = the pair rows' type weights with the self-loop's H = 2 folded in, as the edge kernel writes them).  Layer 2 then
+// runs once per NODE — B*N rows instead of B*N(N+1)/2 — and so does the split into matrix operands; forming S is plain
+// VALU work (N x 128 values per node and type) on rows staged in LDS.  A workgroup owns one 32-node row block: wave w
+// takes hidden tile w of every type (its 4 sub-steps of the type's 16 straight from L2 into registers, requested before
+// the type's VALU work), the scenes' pre-activation rows are staged type by type in a double-buffered LDS stage (one
+// barrier per type), the type weights of the block's rows sit in `efs` ([row][k][16 partners], zero padded), the four
+// waves' partial outputs meet in LDS in a fixed order.
+//
+// relu without a max: there is no packed fp32 max, so e * relu(a + b) is 1 packed add + 2 max + 1 packed fma per value
+// pair.  With s a power of two such that s * |a + b| < 1 for every staged value of the type, relu(a + b) =
+// clamp01(s b + s a) / s is ONE v_pk_fma_f32 with the clamp modifier, and 1/s goes into the type weight: two packed
+// instructions per value pair.  Scaling by powers of two commutes with rounding, so the result is bit-identical to the
+// max form (GN_NODE_CLAMP = 0 builds that one; a type whose largest pre-activation is beyond 2^72 takes it at run time).
+// s comes from the maximum |A| of the staged rows, which the waves record while they stage a type (one slot per wave and
+// buffer, read behind the barrier that publishes the buffer).
+#ifndef GN_NODE_CLAMP
+#define GN_NODE_CLAMP 1
+#endif
+constexpr int kNodeLoads = 8;                        // 16-byte pieces per thread and type of the stage (<= 64 nodes)
+__host__ __device__ __forceinline__ int node_stage_nodes(int N) { return (31 / N + 2) * N; }
+// floats of the launch's dynamic LDS the node form needs: stage buffer 1, efs, the waves' maxima
+__host__ __device__ __forceinline__ int node_form_lds_floats(int N, int K) {
+  return node_stage_nodes(N) * kStagePitch + 32 * (K * 16 + 1) + 12;
+}
+__device__ __forceinline__ f32x2 pk_fma_clamp(f32x2 a, f32x2 b, f32x2 c) {      // clamp01(a * b + c), both halves
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+template <int P, typename T>
+__device__ __forceinline__ void agg_node_body(const gn_agg_group_t& G, int wg, int wave, int lane, const void* img,
+                                              float* stage0, float* dyn, ovf_t& ovf, int unit) {
+  const int N = G.N, E = G.E, K = G.K;
+  const int rowsN = G.rows / E * N;                  // node rows of the group
+  const int h = lane >> 5, r = lane & 31;
+  const int g0 = wg * 32;
+  const int grow = min(g0 + r, rowsN - 1);
+  const int b = grow / N, i = grow - b * N;
+  const int sb0 = g0 / N, sb1 = min(g0 + 31, rowsN - 1) / N;
+  const int node0 = sb0 * N, nodes = (sb1 - sb0 + 1) * N;
+  // LDS: stage buffer 0 = the (here unused) weight ring, buffer 1 and the type weights in the launch's dynamic part —
+  // the launch must keep two workgroups per CU for the groups that run beside this one
+  const int bufsz = node_stage_nodes(N) * kStagePitch;
+  float* const stage1 = dyn;
+  float* const efs = dyn + bufsz;
+  const int efp = K * 16 + 1;                        // floats per row of efs (+1: the rows of a ds_read_b32 on different banks)
+  unsigned* const wmax = reinterpret_cast<unsigned*>(efs + 32 * efp);   // [3][4]: slots k % 3 = max |A| each wave staged of type k
+  const size_t ldA = (size_t)K * 128;
+  const f32x4* Ag = reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(G.A) + (size_t)node0 * ldA);
+  const int total4 = nodes * 32;
+  f32x4 pre[kNodeLoads];
+  auto fetch = [&](int kk) {
+#pragma unroll
+    for (int it = 0; it < kNodeLoads; ++it) {
+      const int idx = min((int)threadIdx.x + it * 256, total4 - 1);
+      if (it * 256 < total4) pre[it] = Ag[(size_t)(idx >> 5) * (ldA / 4) + kk * 32 + (idx & 31)];
+    }
+  };
+  auto commit = [&](int buf, int kk) {              // kk: the type the registers hold
+    float m = 0.f;
+#pragma unroll
+    for (int it = 0; it < kNodeLoads; ++it) {
+      const int idx = (int)threadIdx.x + it * 256;
+      if (it * 256 < total4) {                       // (uniform; clamped loads repeat the last piece: harmless in the max)
+        if (idx < total4)
+          *reinterpret_cast<f32x4*>((buf ? stage1 : stage0) + (idx >> 5) * kStagePitch + (idx & 31) * 4) = pre[it];
+        if constexpr (GN_NODE_CLAMP != 0)
+          m = fmaxf(fmaxf(m, fmaxf(fabsf(pre[it][0]), fabsf(pre[it][1]))), fmaxf(fabsf(pre[it][2]), fabsf(pre[it][3])));
+      }
+    }
+    // wave maximum on DPP moves (a __shfl butterfly is six dependent LDS round trips; LDS atomics on one word serialise
+    // 256 lanes: both measured, thousands of cycles per type), one slot per wave
+    if constexpr (GN_NODE_CLAMP != 0) {
+      auto dpp_max = [&](auto ctrl) {
+        const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), decltype(ctrl)::value, 0xf, 0xf, false);
+        m = fmaxf(m, __builtin_bit_cast(float, o));
+      };
+      dpp_max(std::integral_constant<int, 0xb1>{});    // quad_perm [1,0,3,2]
+      dpp_max(std::integral_constant<int, 0x4e>{});    // quad_perm [2,3,0,1]
+      dpp_max(std::integral_constant<int, 0x141>{});   // row_half_mirror
+      dpp_max(std::integral_constant<int, 0x140>{});   // row_mirror: every lane holds its 16-lane row's maximum
+      const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 0));
+      const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16));
+      const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 32));
+      const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 48));
+      if (lane == 0) wmax[(kk % 3) * 4 + wave] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)));
+    }
+  };
+  fetch(0);
+  // type weights of the block's rows: efs[row * efp + k * 16 + j] = ef[pair(i_row, j), k], 0 for j >= N.  Eight threads
+  // per row, element e = k * 16 + j = (t & 7) + 8 * it; twelve gathers in flight per thread, then their LDS writes (a
+  // load-wait-write loop would pay one L2 round trip per element)
+  {
+    const int rr = (int)threadIdx.x >> 3, sub = (int)threadIdx.x & 7;
+    const int gr = min(g0 + rr, rowsN - 1);
+    const int bb = gr / N, ii = gr - bb * N;
+    const float* efb = G.edge_feat + (size_t)bb * E * K;
+    float* dst = efs + rr * efp + sub;
+    for (int it0 = 0; it0 * 8 < K * 16; it0 += 12) {
+      float v[12];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int e = min(sub + 8 * (it0 + u), K * 16 - 1);
+        const int k = e >> 4, j = e & 15;
+        v[u] = j < N ? efb[(size_t)gn_pair_index(ii, j, N) * K + k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 12; ++u)
+        if ((it0 + u) * 8 < K * 16) dst[8 * (it0 + u)] = v[u];
+    }
+  }
+  commit(0, 0);
+  if (K > 1) fetch(1);
+  __syncthreads();
+  GN_STAMP(unit, 1);
+  __builtin_amdgcn_s_setprio(2);      // (these waves end the launch: their instructions go first where a SIMD is shared)
+  f32x16 out[2];
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[o][q] = 0.f;
+  const f32x4* Wl = reinterpret_cast<const f32x4*>(img) + lane;
+  const int base = (b - sb0) * N;                    // stage row of this lane's scene, node 0
+  const int my = base + i;
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    const float* cb = ((k & 1) ? stage1 : stage0) + 32 * wave;
+    if (k == 1) GN_STAMP(unit, 5);
+    // scale of the clamp form for this type (uniform): s = 2^-(floor(log2 M) + 2) for M = max |A| staged, so that
+    // s |a + b| < 1; M below 2^-27 is treated as 2^-27, M beyond 2^72 (or not finite) takes the max form
+    float sc = 1.f, isc = 1.f;
+    bool clamp_form = false;
+    if constexpr (GN_NODE_CLAMP != 0) {
+      // slots k % 3 were filled while type k was staged (before the barrier that published it); they are next written
+      // while type k + 3 is staged, two barriers from here
+      const u32x4 wm = *reinterpret_cast<const u32x4*>(wmax + (k % 3) * 4);      // (non-negative floats order like their bits)
+      const int eb = max(gn_uniform((int)(max(max(wm[0], wm[1]), max(wm[2], wm[3])) >> 23)), 100);
+      clamp_form = eb <= 199;
+      sc = __builtin_bit_cast(float, (unsigned)(252 - min(eb, 199)) << 23);
+      isc = __builtin_bit_cast(float, (unsigned)(min(eb, 199) + 2) << 23);
+    }
+    if (k + 1 < K) commit((k + 1) & 1, k + 1);       // (that buffer was last read before the barrier that closed type k - 1)
+    if (k + 2 < K) fetch(k + 2);
+    f32x4 w[4][P];                                   // [W2k(0,t) hf0, hf1, W2k(1,t) hf0, hf1] of hidden tile t = wave
+    {
+      const f32x4* wp = Wl + (size_t)((k * 16 + 4 * wave) * P) * 64;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int p = 0; p < P; ++p) w[u][p] = wp[(u * P + p) * 64];
+    }
+    // b2k (wave 0 adds sum_k b2k c[n,k]): requested here, used behind the partner loop — a load waited for where it is
+    // issued would also wait for the weight and stage loads above (vmcnt counts in order): one L2 round trip per type
+    // (every lane loads, the select by wave / half happens at the use: a load under an exec mask into a register that
+    // was zeroed first made the compiler wait for the stage loads above before it)
+    const float* b2k = G.b2 + k * 64 + r;
+    const float bf0 = b2k[0], bf1 = b2k[32];
+    const PreTile a = load_pre(cb + my * kStagePitch, h);
+    if (k == 1) GN_STAMP(unit, 6);
+    f32x2 acc2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc2[q] = f32x2{0.f, 0.f};
+    float csum = 0.f;
+    const float* er = efs + r * efp + k * 16;
+    const float* prow = cb + base * kStagePitch;     // partner 0 of this lane's scene
+    f32x16 acc;
+    // partners in order, the rows and weights of the partner two ahead requested (LDS) before the current one's
+    // arithmetic (one partner's arithmetic is shorter than an LDS round trip); the scheduling barriers keep the
+    // requests where they are written
+    auto partners = [&](auto accumulate) {
+      auto row = [&](int j) { return load_pre(prow + min(j, N - 1) * kStagePitch, h); };
+      auto wgt = [&](int j) { return er[min(j, N - 1)]; };
+      PreTile pA = row(0), pB = row(1), pC;
+      float eA = wgt(0), eB = wgt(1), eC;
+      int j = 0;
+      for (; j + 2 < N; j += 3) {
+        pC = row(j + 2), eC = wgt(j + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        accumulate(pA, eA);
+        pA = row(j + 3), eA = wgt(j + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        accumulate(pB, eB);
+        pB = row(j + 4), eB = wgt(j + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        accumulate(pC, eC);
+      }
+      if (j < N) accumulate(pA, eA);
+      if (j + 1 < N) accumulate(pB, eB);
+    };
+    if (clamp_form) {
+      f32x2 as[8];                                   // s * a
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) as[2 * q + c] = f32x2{a.v[q][2 * c] * sc, a.v[q][2 * c + 1] * sc};
+      const f32x2 s2 = {sc, sc};
+      partners([&](const PreTile& pb, float e) {
+        const float es = e * isc;
+        const f32x2 e2 = {es, es};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const f32x2 rl = pk_fma_clamp(f32x2{pb.v[q][2 * c], pb.v[q][2 * c + 1]}, s2, as[2 * q + c]);   // s relu(a + b)
+            acc2[2 * q + c] = __builtin_elementwise_fma(e2, rl, acc2[2 * q + c]);
+          }
+        csum += e;
+      });
+    } else {
+      partners([&](const PreTile& pb, float e) {
+        const f32x2 e2 = {e, e};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const f32x2 s2 = f32x2{a.v[q][2 * c], a.v[q][2 * c + 1]} + f32x2{pb.v[q][2 * c], pb.v[q][2 * c + 1]};
+            const f32x2 m2 = {fmaxf(s2[0], 0.f), fmaxf(s2[1], 0.f)};
+            acc2[2 * q + c] = __builtin_elementwise_fma(e2, m2, acc2[2 * q + c]);
+          }
+        csum += e;
+      });
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      acc[2 * q] = acc2[q][0];
+      acc[2 * q + 1] = acc2[q][1];
+    }
+    if (k == 1) GN_STAMP(unit, 7);
+    Parts<P> xh[2];
+    make_parts<P>(acc, 0, xh[0], ovf);
+    make_parts<P>(acc, 1, xh[1], ovf);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mfma_substep<P>(w[u], xh[u & 1], out[u >> 1]);
+    if (wave == 0) {                                 // (as add_b2: lane (i, h = 0) carries b2k[32 o + i] against c[row, k])
+      const float cs = h == 0 ? csum : 0.f;
+      out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? bf0 : 0.f, cs, out[0], 0, 0, 0);
+      out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? bf1 : 0.f, cs, out[1], 0, 0, 0);
+    }
+    __syncthreads();                                 // type k + 1 is visible; every wave is past its reads of type k
+  }
+  // partial outputs of the four waves (one hidden tile each) meet in LDS; wave w finishes quads 2w, 2w + 1
+  GN_STAMP(unit, 2);
+  f32x4* lds = reinterpret_cast<f32x4*>(dyn);          // (32 KiB; the launch's dynamic part is at least kAggPartBytes)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 v = {out[q >> 2][4 * (q & 3) + 0], out[q >> 2][4 * (q & 3) + 1], out[q >> 2][4 * (q & 3) + 2],
+                     out[q >> 2][4 * (q & 3) + 3]};
+    lds[(wave * 8 + q) * 64 + lane] = v;
+  }
+  __syncthreads();
+  if (g0 + r < rowsN) {
+    T* yrow = reinterpret_cast<T*>(G.feat) + (size_t)(g0 + r) * GN_FEAT;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int q = wave * 2 + qq;
+      f32x4 v = lds[(0 * 8 + q) * 64 + lane];
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) {
+        const f32x4 t = lds[(ww * 8 + q) * 64 + lane];
+        v[0] += t[0];
+        v[1] += t[1];
+        v[2] += t[2];
+        v[3] += t[3];
+      }
+      st4(yrow + 32 * (q >> 2) + 8 * (q & 3) + 4 * h, v);
+    }
+  }
+  GN_STAMP(unit, 3);
+  GN_STAMP(unit, 4);
+  GN_STAMP(unit, 9);
+}
+
 template <int P, typename T>
 __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4* wring, ovf_t& ovf) {
   using WS = WStream<P>;
@@ -834,6 +1112,12 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
   // (the weight image of this group's form and its flag word)
   const void* img = pair_form ? pick_image<P>(G.W2x, G.W2h) : pick_image<P>(G.W12x, G.W12h);
   if constexpr (P == 2) ovf.wf |= image_flag(img, pair_form ? K * 16 : K * 32);
+  if constexpr (P != 1) {
+    if (pair_form && G.node_form) {      // (block-uniform; the workgroup's four waves share one 32-node row block)
+      agg_node_body<P, T>(G, wg, wave, threadIdx.x & 63, img, reinterpret_cast<float*>(wring), part_dyn, ovf, lwg * 4 + wave);
+      return;
+    }
+  }
   if (pair_form && wpr == 1) {
     // ---- pair form: hid_t = relu(A_i + A_j) * ef_k is VALU work (V_t), its layer-2 slice the matrix work (B_t:
     // one chunk of the stream, 16 sub-steps per type).  wpr == 1, pipelined: V of the NEXT tile (the next type's
@@ -1692,6 +1976,12 @@ __device__ __forceinline__ void mlp2_rows_tile(const gn_mlp2_group_t& G, int row
     return;
   }
   const int E = G.E;
+  if (E == 0) {      // feat already holds H^T feat per node (node form of the typed aggregation)
+    load_row_tile(reinterpret_cast<const T*>(G.feat) + (size_t)row * GN_FEAT + 32 * tile, h, in);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) in[r] = in[r] / divisor;
+    return;
+  }
   const int b = row / N, n = row - b * N;
   f32x16 acc;
 #pragma unroll
@@ -1877,7 +2167,7 @@ __device__ __forceinline__ void mlp2_xs_body(const GroupTable<gn_mlp2_group_t>& 
     if (G.x == nullptr) {
       // all four waves gather: wave w takes rows [16 (w >> 1), 16 (w >> 1) + 16) of feature tile w & 1 (the two halves of a
       // tile meet in `lines`); waves 2 / 3 request their ori tiles first, so those loads fly beside the gather
-      via_lines = G.H != nullptr || G.sym != 0;      // (block-uniform: the group's shape decides)
+      via_lines = (G.H != nullptr || G.sym != 0) && G.E > 0;      // (block-uniform: the group's shape decides)
       if (via_lines) {
         if (wave >= 2) mlp2_rows_tile<T>(G, rb.row_ld, h, N, divisor, IT, wave, in);
         scatter_tile_lines<T, 2>(G, lwg - Tb.first_wg[gi], rows, N, divisor, wave & 1, lane, lines[wave & 1], 2 * (wave >> 1));

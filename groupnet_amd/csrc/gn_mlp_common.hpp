@@ -674,7 +674,10 @@ __device__ __forceinline__ void mlp2_rows(const gn_mlp2_group_t& G, int row, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const T* fb = reinterpret_cast<const T*>(G.feat) + (size_t)b * E * GN_FEAT;
-    if (G.H != nullptr && E <= 16) {
+    if (E == 0) {
+      // feat already holds H^T feat per node (node form of the typed aggregation)
+      load_rows<2>(reinterpret_cast<const T*>(G.feat), GN_FEAT, row, h, acc);
+    } else if (G.H != nullptr && E <= 16) {
       // few hyperedges: read every feat row of the scene (they sit in L1/L2: the scene's lanes share them) weighted by
       // H, four rows in flight — a branch per edge would serialise one memory latency per member
       const float* hcol = G.H + (size_t)b * E * N + n;

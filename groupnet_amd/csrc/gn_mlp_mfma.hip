@@ -1125,6 +1125,10 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
       if (twin) return GN_ERR_SHAPE;
       GN_CHECK(need(G.A, true));
       if (G.N <= 0 || G.E != gn_pair_count(G.N) || G.rows % G.E != 0) return GN_ERR_SHAPE;
+      // node form: layer 2 per node (bf16-core images only; the type weights of a row block fit the weight ring's LDS)
+      if (G.node_form && (!xm || G.N > 16 || G.K > 12)) return GN_ERR_SHAPE;
+    } else if (G.node_form) {
+      return GN_ERR_SHAPE;
     } else if (G.eo != nullptr) {
       GN_CHECK(need(G.eo, true));
     } else {
@@ -1149,18 +1153,21 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
       const int v = atoi(e);
       if (v == 1 || v == 2 || v == 4) wpr = v;
     }
+    if (G.node_form) wpr = 1;
     T.g[g].a = G;
     T.g[g].wpr = wpr;
     // pair form with one wave per row block: stage the scenes' node rows in LDS when they fit
     const bool no_stage = getenv("GN_AGG_NO_STAGE") != nullptr;
-    T.g[g].stage = (!no_stage && G.A != nullptr && wpr == 1 &&
+    T.g[g].stage = (!no_stage && G.A != nullptr && wpr == 1 && !G.node_form &&
                     (127 / G.E + 2) * G.N <= (xm ? kStageMaxNodesX : kStageMaxNodes)) ? 1 : 0;
   }
   // Workgroups are dispatched in index order: give the low indices to the group whose waves run longest
   // (types x layers per wave), so the long waves start first and the short ones fill the tail.
   const bool as_given = getenv("GN_AGG_ORDER_AS_GIVEN") != nullptr;
   if (!as_given) {
-    auto cost = [](const AggGroup& a) { return (long long)a.a.K * (a.a.A != nullptr ? 1 : 2) * 4 / a.wpr; };
+    auto cost = [](const AggGroup& a) {
+      return a.a.node_form ? 1ll : (long long)a.a.K * (a.a.A != nullptr ? 1 : 2) * 4 / a.wpr;
+    };
     for (int i = 1; i < n_groups; ++i)        // insertion sort, stable, n <= GN_MAX_GROUPS
       for (int j = i; j > 0 && cost(T.g[j]) > cost(T.g[j - 1]); --j) {
         const AggGroup tmp = T.g[j];
@@ -1170,7 +1177,9 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
   }
   for (int g = 0; g < n_groups; ++g) {
     T.first_wg[g] = wg;
-    wg += ((T.g[g].a.rows + 31) / 32 * T.g[g].wpr + 3) / 4;
+    const gn_agg_group_t& a = T.g[g].a;
+    wg += a.node_form ? (a.rows / a.E * a.N + 31) / 32      // one workgroup per 32-NODE row block
+                      : ((a.rows + 31) / 32 * T.g[g].wpr + 3) / 4;
   }
   T.first_wg[n_groups] = wg;
   // bf16 storage, a large launch: two row blocks per wave (agg_rb2_kernel)
@@ -1220,7 +1229,14 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
     }
   }
   bool need_part = false;       // LDS for partial sums (wpr > 1), the staged node rows or the line-layout gather
-  for (int g = 0; g < n_groups; ++g) need_part = need_part || T.g[g].wpr > 1 || T.g[g].stage != 0 || T.g[g].lines != 0;
+  for (int g = 0; g < n_groups; ++g) {
+    need_part = need_part || T.g[g].wpr > 1 || T.g[g].stage != 0 || T.g[g].lines != 0;
+    if (T.g[g].a.node_form) {   // second stage buffer of the row block's scenes + the block's type weights
+      const size_t b = (size_t)node_form_lds_floats(T.g[g].a.N, T.g[g].a.K) * sizeof(float);
+      need_part = true;
+      stage_need = b > stage_need ? b : stage_need;
+    }
+  }
   const size_t part_bytes = need_part ? (stage_need > kAggPartBytes ? stage_need : (size_t)kAggPartBytes) : 0;
   if (twin)
     hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
@@ -1318,11 +1334,13 @@ static int mlp2_launch(const gn_mlp2_group_t* groups, int n_groups, int rows, in
     if (G.x != nullptr) {
       GN_CHECK(need(G.x, true));
     } else {
-      if (din != 128 || N <= 0 || !(divisor != 0.f) || rows % N != 0 || G.E <= 0) return GN_ERR_SHAPE;
+      if (din != 128 || N <= 0 || !(divisor != 0.f) || rows % N != 0 || G.E < 0) return GN_ERR_SHAPE;
       GN_CHECK(need(G.feat, true));
       GN_CHECK(need(G.ori, true));
-      if (G.H == nullptr && G.E != (G.sym ? gn_pair_count(N) : N * N)) return GN_ERR_SHAPE;
-      if (G.H != nullptr && G.sym) return GN_ERR_SHAPE;
+      if (G.E > 0) {      // (E == 0: feat is H^T feat per node already)
+        if (G.H == nullptr && G.E != (G.sym ? gn_pair_count(N) : N * N)) return GN_ERR_SHAPE;
+        if (G.H != nullptr && G.sym) return GN_ERR_SHAPE;
+      } else if (G.H != nullptr || G.sym) return GN_ERR_SHAPE;
     }
     GN_CHECK(need(xm ? G.Wx : (const void*)G.W, true));
     GN_CHECK(need(G.bias, true));

@@ -849,11 +849,24 @@ class GatherSpec:
 
 class PairSpec:
     """Pair form of the typed MLP for the pairwise graph: A (B,N,K*128) = node_linear(ori) holds the first
-    layer per node; rows are the N(N+1)/2 unordered pairs.  Uses pk["W2t"] instead of pk["W"]."""
-    __slots__ = ("A",)
+    layer per node; rows are the N(N+1)/2 unordered pairs.  Uses pk["W2t"] instead of pk["W"].
+    ``node=True`` (N <= NODE_FORM_MAX_N, bf16-core images): the NODE form — the per-pair feature is consumed only as
+    H^T feat (model/MS_HGNN_batch.py:267) and type weighting + layer 2 are linear, so layer 2 runs once per node on
+    S[n,k] = sum_j ef[p(n,j),k] relu(A[n,k] + A[j,k]); the result is H^T feat (B,N,64), to be fed to the closing MLP
+    through a ``NodeAggSpec``."""
+    __slots__ = ("A", "node")
 
-    def __init__(self, A: Tensor):
-        self.A = A
+    def __init__(self, A: Tensor, node: bool = False):
+        self.A, self.node = A, bool(node)
+
+
+NODE_FORM_MAX_N = 16
+NODE_FORM_MAX_K = 12
+
+
+def node_form_enabled() -> bool:
+    """GN_NODE_FORM=0 keeps the per-pair form (A/B switch, read per call)."""
+    return os.environ.get("GN_NODE_FORM", "1") != "0"
 
 
 def split_bf16(packed: Tensor, out: Optional[Tensor] = None, parts: int = 3) -> Tensor:
@@ -893,7 +906,10 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
             E = pair_count(N)
             _same_device(A, edge_feat)
             like, eo_ptr, wkey = A, 0, "W2t"
-            extra = (0, 0, E, N, 1, A.data_ptr(), _ximg(pk, "W2t", A.dtype), 0, _himg(pk, "W2t", A.dtype), 0)
+            extra = (0, 0, E, N, 1, A.data_ptr(), _ximg(pk, "W2t", A.dtype), 0, _himg(pk, "W2t", A.dtype), 0,
+                     1 if eo.node else 0)
+            if eo.node and (N > NODE_FORM_MAX_N or K > NODE_FORM_MAX_K or not extra[6]):
+                raise ValueError("PairSpec(node=True): needs N <= 16, K <= 12 and the bf16-core weight images")
         elif isinstance(eo, GatherSpec):
             ori, H = eo.ori, eo.H
             _req(ori, "ori", (None, None, FEAT), _ACT_DTYPES)
@@ -913,12 +929,17 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
         if like.device != dev0 or like.dtype != dt:
             raise ValueError("grouped launch: every group must be on the same device and of the same storage type")
         _req(edge_feat, "edge_feat", (B, E, K))
-        feat = torch.empty((B, E, FEAT), dtype=like.dtype, device=like.device)
+        node = isinstance(eo, PairSpec) and eo.node
+        feat = torch.empty((B, N if node else E, FEAT), dtype=like.dtype, device=like.device)
         arr[g] = _lib.AggGroup(eo_ptr, edge_feat.data_ptr(), pk[wkey].data_ptr(), pk["b1"].data_ptr(),
                                pk["b2"].data_ptr(), feat.data_ptr(), B * E, K, *extra)
         outs.append(feat)
-        # executed FLOPs: both layers, or the second layer only in the pair form
-        flops += B * E * K * ((2 * 128 * 64 + 2 * 64) + (0 if wkey == "W2t" else 2 * 64 * 128))
+        # executed FLOPs: both layers, or the second layer only in the pair form; node form: layer 2 per node plus the
+        # 3 flops (add, max, fma) per pair-member and hidden value that form S
+        if node:
+            flops += B * N * K * (2 * 128 * 64 + 2 * 64) + B * N * N * K * 128 * 3
+        else:
+            flops += B * E * K * ((2 * 128 * 64 + 2 * 64) + (0 if wkey == "W2t" else 2 * 64 * 128))
     with torch.cuda.device(dev0), _Probed("agg_mlp_kernel", flops):
         check(_fn("gn_agg_mlp", dt)(arr, len(items), stream_handle()), "gn_agg_mlp")
     return outs
@@ -997,6 +1018,15 @@ class ScatterSpec:
         self.feat, self.H, self.ori, self.sym, self.divisor = feat, H, ori, bool(sym), divisor
 
 
+class NodeAggSpec:
+    """Input rows of a 128-wide MLP formed inside the kernel from H^T feat per NODE (the node form of the typed
+    aggregation, ``PairSpec(node=True)``) and ori: cat(agg, ori) / divisor (divisor defaults to N)."""
+    __slots__ = ("agg", "ori", "divisor")
+
+    def __init__(self, agg: Tensor, ori: Tensor, divisor: Optional[float] = None):
+        self.agg, self.ori, self.divisor = agg, ori, divisor
+
+
 def mlp2_grouped(items: Sequence[Tuple[object, dict, Optional[Tensor]]], keep: Optional[List[dict]] = None
                  ) -> List[Tensor]:
     """items = [(x (..., din) or ScatterSpec, pk{"W","bias","din","dh","dout"}, out or None)], same
@@ -1012,7 +1042,20 @@ def mlp2_grouped(items: Sequence[Tuple[object, dict, Optional[Tensor]]], keep: O
     for g, (x, pk, out) in enumerate(items):
         if (pk["din"], pk["dh"], pk["dout"]) != (din, dh, dout):
             raise ValueError("grouped mlp2: every group must have the same layer widths")
-        if isinstance(x, ScatterSpec):
+        if isinstance(x, NodeAggSpec):
+            if din != 2 * FEAT:
+                raise ValueError("NodeAggSpec feeds a 128-wide MLP")
+            _req(x.ori, "ori", (None, None, FEAT), _ACT_DTYPES)
+            B, Nn, _ = x.ori.shape
+            _req(x.agg, "agg", (B, Nn, FEAT), x.ori.dtype)
+            _same_device(x.ori, x.agg)
+            d = float(Nn if x.divisor is None else x.divisor)
+            if N and (N, divisor) != (Nn, d):
+                raise ValueError("grouped mlp2: every fused-scatter group must share N and divisor")
+            N, divisor = Nn, d
+            lead, like = (B, Nn), x.ori
+            fields = (0, pk["W"].data_ptr(), pk["bias"].data_ptr(), None, x.agg.data_ptr(), 0, x.ori.data_ptr(), 0, 0)
+        elif isinstance(x, ScatterSpec):
             if din != 2 * FEAT:
                 raise ValueError("ScatterSpec feeds a 128-wide MLP")
             _req(x.ori, "ori", (None, None, FEAT), _ACT_DTYPES)

@@ -360,6 +360,13 @@ typedef struct {
                          A0 A1 B0 A2 B1 A3 B2 B3 (32 sub-steps per type).  With W2x / W12x, W may be NULL. */
   const void* W2h;    /* optional fp16 two-part images of the same streams as W2x / W12x (f16x3 path; need those too) */
   const void* W12h;
+  int node_form;      /* pair form with W2x, N <= 16, K <= 12 only.  Nothing downstream of edge_aggregation.forward reads the
+                         per-edge feature: MS_HGNN_batch.py:267 consumes it as H^T feat, and both the type weighting and
+                         layer 2 are linear, so they commute with that sum.  With node_form = 1 the kernel evaluates
+                           S[n,k] = sum_j edge_feat[p(n,j),k] relu(A[n,k] + A[j,k]),  c[n,k] = sum_j edge_feat[p(n,j),k]
+                           (H^T feat)[n] = sum_k (W2k S[n,k] + b2k c[n,k])
+                         i.e. layer 2 once per NODE (B*N rows) instead of once per pair (B*N(N+1)/2 rows), and `feat`
+                         receives (H^T feat) (B*N, 64) — what gn_mlp2_f32 takes with E = 0.  rows stays B*E. */
 } gn_agg_group_t;
 int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream);
 /* twin: two-layer form only (eo, or the fused gather from ori) — a per-node first layer stored in bf16 would
@@ -424,7 +431,9 @@ int gn_agg_scatter_bf16(const gn_scatter_group_t* groups, int n_groups, int B, i
  * Fused scatter (x == NULL, din == 128): the kernel forms its input rows itself exactly as
  * gn_agg_scatter_f32 would — row b*N + n is cat(sum_e H[b,e,n] feat[b,e], ori[b,n]) / divisor
  * (H (B,E,N); H == NULL: the pairwise graph, E = N*N ordered edges or, sym = 1, E = N(N+1)/2 pair
- * sums) — so the (B,N,128) aggregate never exists in HBM.  rows must equal B*N. */
+ * sums) — so the (B,N,128) aggregate never exists in HBM.  rows must equal B*N.
+ * E == 0 (x == NULL): `feat` already holds H^T feat per node, (rows, 64) — the output of gn_agg_mlp_f32's node form;
+ * the input row is cat(feat[row], ori[row]) / divisor. */
 typedef struct {
   const float* x;      /* [T] */
   const float* W;

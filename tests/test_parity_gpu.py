@@ -1424,3 +1424,112 @@ def test_copy_cols_equals_torch_copy(dtype):
         dst = torch.zeros(37, 11, hi - lo, device=dev(), dtype=dtype)
         ops.copy_cols(dst, src)
         assert torch.equal(dst, src.contiguous()), (lo, hi)
+
+
+# ---------------------------------------------------------------------------------------------
+# node form of the pairwise typed aggregation (gn_agg_group_t.node_form): layer 2 once per node
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6"])
+@pytest.mark.parametrize("B,N", [(37, 11), (512, 11), (5, 1), (9, 2), (7, 16), (3, 5), (130, 13)])
+def test_node_form_equals_scattered_pair_form(B, N, precision):
+    """edge_aggregation.forward consumes the per-edge feature only as H^T feat (model/MS_HGNN_batch.py:267): the node
+    form evaluates that sum directly, layer 2 once per node.  Against the pair form scattered by gn_agg_scatter (which the
+    goldens pin), ragged row blocks, one to three scenes per row block, both matrix paths."""
+    from groupnet_amd import ops
+    torch.manual_seed(300 + N)
+    pair, _ = build_modules(1)
+    pair.to(dev())
+    agg = pair.edge_aggregation_list[0]
+    K = pair.edge_types
+    pk = agg._packed()
+    ori = torch.randn(B, N, 64, device=dev()) * 1.5
+    ef = torch.rand(B, ops.pair_count(N), K, device=dev())
+    A = ops.node_linear(ori, pk["W1cat"], pk["b1half"], K * 128)
+    old = ops.precision()
+    ops.set_precision(precision)
+    try:
+        (feat,) = ops.agg_mlp_grouped([(ops.PairSpec(A), ef, pk, K)])
+        (node,) = ops.agg_mlp_grouped([(ops.PairSpec(A, node=True), ef, pk, K)])
+    finally:
+        ops.set_precision(old)
+    assert node.shape == (B, N, 64)
+    want = ops.agg_scatter(feat, None, ori, divisor=1.0, sym=True)[..., :64]      # H^T feat
+    scale = max(1.0, float(want.abs().max()))
+    err = maxerr(node, want)
+    print(f"node form vs scattered pair form, B={B} N={N} {precision}: {err:.2e} (scale {scale:.2e})")
+    assert err <= 2e-6 * scale
+
+
+def test_node_form_feeds_the_closing_mlp_like_the_fused_scatter():
+    """gn_mlp2_f32 with E = 0 (feat already per node) == the fused scatter of the pair rows."""
+    from groupnet_amd import ops
+    torch.manual_seed(77)
+    pair, _ = build_modules(1)
+    pair.to(dev())
+    B, N, K = 41, 11, pair.edge_types
+    pk = pair.edge_aggregation_list[0]._packed()
+    ori = torch.randn(B, N, 64, device=dev())
+    ef = torch.rand(B, ops.pair_count(N), K, device=dev())
+    A = ops.node_linear(ori, pk["W1cat"], pk["b1half"], K * 128)
+    (feat,) = ops.agg_mlp_grouped([(ops.PairSpec(A), ef, pk, K)])
+    (node,) = ops.agg_mlp_grouped([(ops.PairSpec(A, node=True), ef, pk, K)])
+    pk2 = pair._packed_mlp2(pair.nmp_mlp_end)
+    for xs in ("1", "0"):
+        os.environ["GN_MLP2_XS"] = xs
+        try:
+            (ya,) = ops.mlp2_grouped([(ops.ScatterSpec(feat, None, ori, True), pk2, None)])
+            (yb,) = ops.mlp2_grouped([(ops.NodeAggSpec(node, ori), pk2, None)])
+        finally:
+            os.environ.pop("GN_MLP2_XS", None)
+        assert maxerr(ya, yb) <= 2e-6 * max(1.0, float(ya.abs().max())), xs
+
+
+def test_node_form_clamp_scaling_is_exact_and_has_a_fallback():
+    """The node form evaluates relu(a + b) as clamp01(s a + s b) / s with s a power of two chosen from the largest staged
+    pre-activation: results must not depend on the magnitude class of the inputs beyond fp32 rounding — tiny (below the
+    2^-27 floor of the scale), ordinary, large (bf16x6 fallback of the range vote), and beyond 2^72 where the kernel takes
+    the max form — each against the scattered pair form."""
+    from groupnet_amd import ops
+    torch.manual_seed(5)
+    pair, _ = build_modules(1)
+    pair.to(dev())
+    B, N, K = 19, 11, pair.edge_types
+    pk = pair.edge_aggregation_list[0]._packed()
+    ef = torch.rand(B, ops.pair_count(N), K, device=dev())
+    base = torch.randn(B, N, K * 128, device=dev())
+    for mag in (1e-12, 1.0, 3e4, 1e9, 1e24):
+        A = (base * mag).contiguous()
+        (feat,) = ops.agg_mlp_grouped([(ops.PairSpec(A), ef, pk, K)])
+        (node,) = ops.agg_mlp_grouped([(ops.PairSpec(A, node=True), ef, pk, K)])
+        want = ops.agg_scatter(feat, None, torch.zeros(B, N, 64, device=dev()), divisor=1.0, sym=True)[..., :64]
+        assert bool(torch.isfinite(node).all()), mag
+        scale = float(want.abs().max())
+        assert maxerr(node, want) <= 3e-6 * scale + 1e-30, (mag, maxerr(node, want), scale)
+
+
+def test_node_form_switch_changes_the_path_not_the_result(monkeypatch):
+    """GN_NODE_FORM is read per call: 0 keeps the per-pair form (feat (B,E,64) + fused scatter), 1 the node form; the
+    block's outputs agree to fp32 rounding and the typed-aggregation launch really differs (its output shape)."""
+    import groupnet_amd as G
+    from groupnet_amd import ops
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    torch.manual_seed(9)
+    blk = MultiScaleHGNN([2, 5, 11]).to(dev()).eval()
+    f = torch.randn(64, 11, 64, device=dev())
+    shapes, outs = {}, {}
+    real = ops.agg_mlp_grouped
+
+    def spy(items):
+        r = real(items)
+        shapes[os.environ.get("GN_NODE_FORM", "1")] = tuple(r[0].shape)
+        return r
+    monkeypatch.setattr(ops, "agg_mlp_grouped", spy)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GN_NODE_FORM", mode)
+        G.set_noise_mode("device", seed=11)
+        with torch.no_grad():
+            outs[mode] = blk(f)
+    G.set_noise_mode("host")
+    assert shapes["0"] == (64, 66, 64) and shapes["1"] == (64, 11, 64)
+    a, b = outs["0"][0], outs["1"][0]
+    assert maxerr(a, b) <= 1e-6 * max(1.0, float(a.abs().max()))

@@ -41,6 +41,8 @@ def report(tag, n_units, groups=None):
         tail = u[:, 4] - u[:, 2]
         mid = u[:, 3] - u[:, 2]
         epi = u[:, 4] - u[:, 3]
+        if (u[:, 5] > 0).all() and (u[:, 7] > u[:, 5]).all():
+            print(f"  {name:10s} type-1 iteration: top->partners done {np.median(u[:, 6] - u[:, 5]):6.0f}  ->MFMAs issued {np.median(u[:, 7] - u[:, 6]):6.0f} cycles")
         print(f"  {name:10s} n={len(u):5d} start med/max {np.median(start):5.2f}/{start.max():5.2f}  end med/max {np.median(end):5.2f}/{end.max():5.2f} us |"
               f" cycles: prologue {np.median(pro):6.0f}  body med {np.median(body):6.0f} min {body.min():6.0f} max {body.max():6.0f}  tail {np.median(tail):6.0f} (2->3 {np.median(mid):6.0f}, 3->4 {np.median(epi):6.0f})")
 
@@ -57,7 +59,7 @@ def wrap(name, n_units_fn, groups_fn=None):
     setattr(ops, name, w)
 
 NCH = 704
-wrap("node_stage_grouped", lambda items, keep, specs: 8192 if B > 512 else NCH + 1056, (lambda *a: None) if B > 512 else (lambda *a: [("chain", slice(0, NCH)), ("A", slice(NCH, NCH + 1056))]))
+wrap("node_stage_grouped", lambda items, keep, specs, *rest: 8192 if B > 512 else NCH + 1056, (lambda *a: None) if B > 512 else (lambda *a: [("chain", slice(0, NCH)), ("A", slice(NCH, NCH + 1056))]))
 def edge_rows(e):
     if isinstance(e, ops.PoolSpec):       # rows formed inside the kernel: unordered pairs / hyperedges
         Bn, Nn = e.xp.shape[0], e.xp.shape[1]
@@ -66,7 +68,9 @@ def edge_rows(e):
 def edge_units(items, *a, **k):
     return sum(((edge_rows(it[0]) + 127) // 128) * 4 for it in items)
 wrap("edge_mlp_gumbel_grouped", (lambda *a, **k: 8192) if B > 512 else edge_units, (lambda *a, **k: None) if B > 512 else (lambda items, *a, **k: [("pair", slice(0, 1056)), ("hyper", slice(1056, 1056 + 400))]))
-wrap("agg_mlp_grouped", lambda items: 8192 if B > 512 else 4 * 700, (lambda items: None) if B > 512 else (lambda items: [("hyperA", slice(0, 352)), ("hyperB", slice(352, 704)), ("pair", slice(704, 1760)), ("small", slice(1760, 1824))]))
+wrap("agg_mlp_grouped", lambda items: 8192 if B > 512 else 4 * 700, (lambda items: None) if B > 512 else (lambda items: [("hyperA", slice(0, 352)), ("hyperB", slice(352, 704)), ("small", slice(704, 768)), ("node", slice(768, 1472))]
+                                   if any(isinstance(it[0], ops.PairSpec) and it[0].node for it in items) else
+                                   [("hyperA", slice(0, 352)), ("hyperB", slice(352, 704)), ("pair", slice(704, 1760)), ("small", slice(1760, 1824))]))
 wrap("mlp2_grouped", lambda items, keep=None: 8192 if B > 512 else (4 * 176 * 4 if os.environ.get("GN_MLP2_XS", "1") != "0" else 4 * 44 * 4), None)
 M.ops = ops
 with torch.no_grad():
