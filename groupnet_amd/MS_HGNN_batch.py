@@ -660,19 +660,27 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
                 src = ops.PairSpec(pair_A[i], node=(ops.node_form_enabled() and ops.BF16X6 and N <= ops.NODE_FORM_MAX_N
                                                      and K <= ops.NODE_FORM_MAX_K and N <= _FUSED_SCATTER_MAX_N))
             elif syms[i]:
-                src = ops.GatherSpec(oris[i], None, True)     # bf16 twin: both layers per unordered pair
+                # bf16 twin: both layers per NODE, one scene per workgroup (node form), or per unordered pair
+                src = ops.GatherSpec(oris[i], None, True,
+                                     node=twin and ops.node_form_enabled() and N <= ops.SCENE_FORM_MAX_N)
             elif N <= _FUSED_GATHER_MAX_N:
                 src = ops.GatherSpec(oris[i], Hs[i], False)   # eo = H @ ori formed inside the kernel
             else:
                 src = eos[i]
             items.append((src, edge_feats[i], pk, K))
         feats = ops.agg_mlp_grouped(items)
+
+        def node_item(it) -> bool:
+            return isinstance(it[0], (ops.PairSpec, ops.GatherSpec)) and it[0].node
         if N <= _FUSED_SCATTER_MAX_N:
             # cat(H^T feat, ori) / N is formed inside the MLP kernel that consumes it (node form: H^T feat is what the
             # aggregation kernel wrote)
-            return [ops.NodeAggSpec(f, o) if (isinstance(it[0], ops.PairSpec) and it[0].node) else ops.ScatterSpec(f, H, o, sy)
+            return [ops.NodeAggSpec(f, o) if node_item(it) else ops.ScatterSpec(f, H, o, sy)
                     for f, H, o, sy, it in zip(feats, Hs, oris, syms, items)]
-        return ops.agg_scatter_grouped([(f, H, o, sy) for f, H, o, sy in zip(feats, Hs, oris, syms)])
+        # larger graphs: one stand-alone scatter launch for the modules whose aggregation wrote per-edge features
+        rest = [i for i in range(n) if not node_item(items[i])]
+        scat = dict(zip(rest, ops.agg_scatter_grouped([(feats[i], Hs[i], oris[i], syms[i]) for i in rest]))) if rest else {}
+        return [scat[i] if i in scat else ops.NodeAggSpec(feats[i], oris[i]) for i in range(n)]
 
     res = edge_mlp([m.nmp_mlp_start for m in mods], node2edge(hs, 0), True)
     edge_feats, factors = [r[0] for r in res], [r[1] for r in res]

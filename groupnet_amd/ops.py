@@ -840,11 +840,17 @@ def agg_gather(ori: Tensor, H: Optional[Tensor], sym: bool = False) -> Tensor:
 
 class GatherSpec:
     """Input rows of the typed MLP to be formed inside the kernel instead of read from an `eo` tensor:
-    eo = H @ ori (H (B,E,N)), or the pairwise rows ori_i + ori_j (H=None; sym -> unordered pairs)."""
-    __slots__ = ("ori", "H", "sym")
+    eo = H @ ori (H (B,E,N)), or the pairwise rows ori_i + ori_j (H=None; sym -> unordered pairs).
+    ``node=True`` (bf16 twins, pairwise graph, unordered pairs, N <= SCENE_FORM_MAX_N): the NODE form with one scene per
+    workgroup — both layers run once per node (layer 1 is linear in the two nodes, layer 2 and the type weighting commute
+    with H^T, see PairSpec); the result is H^T feat (B,N,64) for a ``NodeAggSpec``."""
+    __slots__ = ("ori", "H", "sym", "node")
 
-    def __init__(self, ori: Tensor, H: Optional[Tensor], sym: bool = False):
-        self.ori, self.H, self.sym = ori, H, bool(sym)
+    def __init__(self, ori: Tensor, H: Optional[Tensor], sym: bool = False, node: bool = False):
+        self.ori, self.H, self.sym, self.node = ori, H, bool(sym), bool(node)
+
+
+SCENE_FORM_MAX_N = 64
 
 
 class PairSpec:
@@ -917,8 +923,10 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
             E = _edge_count(H, B, N, eo.sym)
             _same_device(ori, H, edge_feat)
             like, eo_ptr = ori, 0
+            if eo.node and not (_twin(ori.dtype) and H is None and eo.sym and N <= SCENE_FORM_MAX_N):
+                raise ValueError("GatherSpec(node=True): bf16 storage, the pairwise graph's unordered pairs and N <= 64")
             extra = (ori.data_ptr(), 0 if H is None else H.data_ptr(), E, N, int(eo.sym), 0, 0,
-                     _ximg(pk, "W12", ori.dtype), 0, _himg(pk, "W12", ori.dtype))
+                     _ximg(pk, "W12", ori.dtype), 0, _himg(pk, "W12", ori.dtype), 1 if eo.node else 0)
         else:
             _req(eo, "eo", (None, None, FEAT), _ACT_DTYPES)
             B, E, _ = eo.shape
@@ -929,7 +937,7 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
         if like.device != dev0 or like.dtype != dt:
             raise ValueError("grouped launch: every group must be on the same device and of the same storage type")
         _req(edge_feat, "edge_feat", (B, E, K))
-        node = isinstance(eo, PairSpec) and eo.node
+        node = isinstance(eo, (PairSpec, GatherSpec)) and eo.node
         feat = torch.empty((B, N if node else E, FEAT), dtype=like.dtype, device=like.device)
         arr[g] = _lib.AggGroup(eo_ptr, edge_feat.data_ptr(), pk[wkey].data_ptr(), pk["b1"].data_ptr(),
                                pk["b2"].data_ptr(), feat.data_ptr(), B * E, K, *extra)
@@ -937,7 +945,8 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
         # executed FLOPs: both layers, or the second layer only in the pair form; node form: layer 2 per node plus the
         # 3 flops (add, max, fma) per pair-member and hidden value that form S
         if node:
-            flops += B * N * K * (2 * 128 * 64 + 2 * 64) + B * N * N * K * 128 * 3
+            flops += (B * N * K * ((2 * 128 * 64 + 2 * 64) + (0 if wkey == "W2t" else 2 * 64 * 128))
+                      + B * N * N * K * 128 * 3)
         else:
             flops += B * E * K * ((2 * 128 * 64 + 2 * 64) + (0 if wkey == "W2t" else 2 * 64 * 128))
     with torch.cuda.device(dev0), _Probed("agg_mlp_kernel", flops):

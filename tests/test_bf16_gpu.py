@@ -70,7 +70,9 @@ def test_bf16_block_matches_fp32_oracle(B, N, scales, rb2, monkeypatch):
         # the launcher's OWN choice of the two-row-blocks kernels (row-block pairs >= threshold), with the threshold
         # lowered by the test knob GN_RB2_MIN_PAIRS so that it is met at a size the oracle can follow (config 4 itself
         # has 20 k pairs against the default 2048)
-        monkeypatch.setenv("GN_RB2_MIN_PAIRS", "16")
+        # (8: the typed aggregation counts only the groups that run on row-block pairs — the pairwise module runs its
+        # scene form there — i.e. the 4 x 3 pairs of the hyper modules)
+        monkeypatch.setenv("GN_RB2_MIN_PAIRS", "8")
     elif rb2 is not None:
         monkeypatch.setenv("GN_AGG_RB2", rb2)
         monkeypatch.setenv("GN_EDGE_RB2", rb2)
@@ -284,3 +286,34 @@ def _offsets(blk, B, N):
         offs.append(cur)
         cur += b * e * k
     return offs
+
+
+@pytest.mark.parametrize("B,N", [(3, 50), (5, 33), (4, 64), (6, 20), (2, 1), (70, 50)])
+def test_scene_form_of_the_twins_matches_the_per_pair_twin_and_fp32(B, N):
+    """Node form of the pairwise typed aggregation on bf16 storage, one scene per workgroup (gn_agg_group_t.node_form
+    without A): both layers once per NODE.  Against the fp32 path on the same bf16-rounded inputs (pair form + scatter,
+    which the goldens pin) within the twins' gate, and not worse than the per-pair twin it replaces; one and two row
+    blocks of nodes per scene, N = 64 (the limit), N = 1."""
+    from groupnet_amd import ops
+    torch.manual_seed(900 + N)
+    import groupnet_amd as G
+    pair = G.MS_HGNN_oridinary(embedding_dim=16, h_dim=64, mlp_dim=64, bottleneck_dim=64, batch_norm=0, nmp_layers=1).to(dev())
+    agg = pair.edge_aggregation_list[0]
+    K = pair.edge_types
+    pk = agg._packed()
+    ori = (torch.randn(B, N, 64, device=dev()) * 1.5).bfloat16()
+    ef = torch.rand(B, ops.pair_count(N), K, device=dev())
+    # fp32 reference: per-pair form on the up-cast inputs, scattered
+    o32 = ori.float()
+    A = ops.node_linear(o32, pk["W1cat"], pk["b1half"], K * 128)
+    (feat32,) = ops.agg_mlp_grouped([(ops.PairSpec(A), ef, pk, K)])
+    want = ops.agg_scatter(feat32, None, o32, divisor=1.0, sym=True)[..., :64]
+    (node,) = ops.agg_mlp_grouped([(ops.GatherSpec(ori, None, True, node=True), ef, pk, K)])
+    assert node.shape == (B, N, 64) and node.dtype == torch.bfloat16
+    (feat16,) = ops.agg_mlp_grouped([(ops.GatherSpec(ori, None, True), ef, pk, K)])
+    old = ops.agg_scatter(feat16, None, ori, divisor=1.0, sym=True)[..., :64]
+    scale = float(want.abs().max())
+    e_new, e_old = float((node.float() - want).abs().max()) / scale, float((old.float() - want).abs().max()) / scale
+    print(f"\nscene form B={B} N={N}: rel err vs fp32 {e_new:.2e} (per-pair twin {e_old:.2e}; gate {TOL_ORACLE:g})")
+    assert e_new <= TOL_ORACLE
+    assert e_new <= 1.5 * e_old + 2e-3
