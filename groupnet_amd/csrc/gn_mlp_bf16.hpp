@@ -1074,34 +1074,40 @@ __device__ __forceinline__ void agg_node_body(const gn_agg_group_t& G, int wg, i
 //      min(f(j) + n, f(n) + j), f(m) = m (N - 1) - m (m - 1) / 2: no branch), clamp form as in agg_node_body,
 //   3. applies W2k to S (bf16 operand, as the twins do) — B*N rows of matrix work per layer instead of B*N(N+1)/2.
 // The weights are the two-layer image of the twins (pipeline order: A_w and B_w of each type), straight from L2.
-constexpr int kSceneRows = 64;
+#ifndef GN_SCENE_OCC
+#define GN_SCENE_OCC 3          // workgroups per CU the scene-form kernel is compiled for (register budget 512 / occupancy)
+#endif
+// floats of dynamic LDS: the stage (N rows), two columns of pair weights, the waves' maxima — and at least the 32 KiB the
+// partial outputs need at the end
 __host__ __device__ __forceinline__ int node_scene_lds_floats(int N) {
   const int EP = (N * (N + 1) / 2 + 3) & ~3;
-  return kSceneRows * kStagePitch + 2 * EP + 8;
+  const int need = N * kStagePitch + 2 * EP + 8;
+  return need > 8192 ? need : 8192;
 }
+// One workgroup per (scene, 32-node row block): the VALU work of step 2 is what bounds this form, a wave issues an
+// instruction every ~5-10 cycles whatever its neighbours do, and the matrix-core kernels' 256 registers allow two waves
+// per SIMD — so the form has its own kernel, compiled for GN_SCENE_OCC workgroups per CU (measured inside
+// agg_rb2_kernel, two per CU: 250 us for the pairwise module of config 4).  Every workgroup of a scene forms A' for all
+// of the scene's nodes (matrix work, cheap) and S / layer 2 for its own row block.
 template <typename T>
-__device__ __forceinline__ void agg_node_scene_body(const gn_agg_group_t& G, int wg, int wave, int lane, float* dyn) {
+__global__ __launch_bounds__(256, GN_SCENE_OCC) void agg_scene_kernel(gn_agg_group_t G) {
   constexpr int P = 1;
+  extern __shared__ __align__(16) float dyn[];
   ovf_t ovf_unused = {0ull, 0};
   const int N = G.N, E = G.E, K = G.K;
-  const int h = lane >> 5, r = lane & 31;
-  const int RBN = (N + 31) >> 5;                       // row blocks of nodes: 1 or 2 (block-uniform)
+  const int RBN = (N + 31) >> 5;                       // row blocks of nodes per scene: 1 or 2
+  const int scene = blockIdx.x / RBN, rbI = blockIdx.x - scene * RBN;
+  const int wave = wave_id();
+  const int lane = threadIdx.x & 63, h = lane >> 5, r = lane & 31;
   const int EP = (E + 3) & ~3;
-  float* const stage = dyn;                            // [64][kStagePitch]: A' of the current type
-  float* const efk = dyn + kSceneRows * kStagePitch;   // [2][EP]: the scene's pair weights of the current / next type
+  float* const stage = dyn;                            // [N][kStagePitch]: A' of the current type
+  float* const efk = dyn + N * kStagePitch;            // [2][EP]: the scene's pair weights of the current / next type
   unsigned* const wmax = reinterpret_cast<unsigned*>(efk + 2 * EP);      // [4]: max |A'| each wave wrote (bits)
-  const T* ori = reinterpret_cast<const T*>(G.ori) + (size_t)wg * N * GN_FEAT;
-  const float* efb = G.edge_feat + (size_t)wg * E * K;
+  const T* ori = reinterpret_cast<const T*>(G.ori) + (size_t)scene * N * GN_FEAT;
+  const float* efb = G.edge_feat + (size_t)scene * E * K;
   const f32x4* Wl = reinterpret_cast<const f32x4*>(G.W12x) + lane;
   // this wave's sub-steps of type k in the pipeline-ordered image: A_w (layer 1, hidden tile w), B_w (its layer-2 slice)
   const int offA = pipe_off_A(wave, 4, 4), offB = pipe_off_B(wave, 4, 4, 4);
-  Parts<P> xi[2][2][2];                                // [row block][input tile][half]
-#pragma unroll
-  for (int rbI = 0; rbI < 2; ++rbI) {
-    f32x16 in[2];
-    load_rows<2>(ori, GN_FEAT, min(rbI * 32 + r, N - 1), h, in);
-    make_parts_tiles<P, 2>(in, xi[rbI], ovf_unused);
-  }
   constexpr int kEfLoads = 9;                          // E <= 2080 (N <= 64) over 256 threads
   float efr[kEfLoads];
   auto ef_fetch = [&](int kk) {
@@ -1114,47 +1120,50 @@ __device__ __forceinline__ void agg_node_scene_body(const gn_agg_group_t& G, int
     for (int it = 0; it < kEfLoads; ++it)
       if (it * 256 < E && (int)threadIdx.x + it * 256 < E) efk[buf * EP + threadIdx.x + it * 256] = efr[it];
   };
-  f32x4 wa[4][P], wb[4][P];
-  auto w_fetch = [&](f32x4 (&w)[4][P], int kk, int off) {
+  f32x4 w[4][P];                                       // A_w during step 1, B_w during steps 2 / 3
+  auto w_fetch = [&](int kk, int off) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) w[u][0] = Wl[(size_t)(kk * 32 + off + u) * 64];
   };
   ef_fetch(0);
-  w_fetch(wa, 0, offA);
-  f32x16 out[2][2];
+  w_fetch(0, offA);
+  f32x16 out[2];
 #pragma unroll
-  for (int rbI = 0; rbI < 2; ++rbI)
+  for (int o = 0; o < 2; ++o)
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) out[rbI][o][q] = 0.f;
-  // pair index of (row n, partner j): min(f(j) + n, f(n) + j)
-  int fn[2];
-#pragma unroll
-  for (int rbI = 0; rbI < 2; ++rbI) {
-    const int n = min(rbI * 32 + r, N - 1);
-    fn[rbI] = n * (N - 1) - n * (n - 1) / 2;
-  }
+    for (int q = 0; q < 16; ++q) out[o][q] = 0.f;
+  const int n = min(rbI * 32 + r, N - 1);              // this lane's node (clamped: dead rows compute, never store)
+  const int fn = n * (N - 1) - n * (n - 1) / 2;        // pair index of (n, j): min(f(j) + n, f(n) + j)
 #pragma unroll 1
   for (int k = 0; k < K; ++k) {
-    // ---- 1. layer 1 per node: hidden tile `wave` of type k for the scene's row blocks -> the stage
+    // ---- 1. layer 1 per node: hidden tile `wave` of type k for ALL the scene's nodes -> the stage
     {
       f32x16 b1h = load_bias_tile(G.b1 + k * 128 + 32 * wave, h);
 #pragma unroll
       for (int q = 0; q < 16; ++q) b1h[q] *= 0.5f;
       float m = 0.f;
 #pragma unroll
-      for (int rbI = 0; rbI < 2; ++rbI)
-        if (rbI < RBN) {
+      for (int rb = 0; rb < 2; ++rb)
+        if (rb < RBN) {
+          // (the scene's ori rows as operands: re-read per type — L2 hits beside other waves' work — instead of 32
+          // resident registers, which this kernel's register budget does not have)
+          Parts<P> xi[2][2];
+          {
+            f32x16 in[2];
+            load_rows<2>(ori, GN_FEAT, min(rb * 32 + r, N - 1), h, in);
+            make_parts_tiles<P, 2>(in, xi, ovf_unused);
+          }
           f32x16 hid = b1h;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) mfma_substep<P>(wa[u], xi[rbI][u >> 1][u & 1], hid);
-          float* dst = stage + (rbI * 32 + r) * kStagePitch + 32 * wave + 4 * h;
+          for (int u = 0; u < 4; ++u) mfma_substep<P>(w[u], xi[u >> 1][u & 1], hid);
+          if (rb * 32 + r < N) {
+            float* dst = stage + (rb * 32 + r) * kStagePitch + 32 * wave + 4 * h;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 v = {hid[4 * q], hid[4 * q + 1], hid[4 * q + 2], hid[4 * q + 3]};
-            *reinterpret_cast<f32x4*>(dst + 8 * q) = v;
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 v = {hid[4 * q], hid[4 * q + 1], hid[4 * q + 2], hid[4 * q + 3]};
+              *reinterpret_cast<f32x4*>(dst + 8 * q) = v;
+              m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            }
           }
         }
       ef_commit(k & 1);
@@ -1172,11 +1181,11 @@ __device__ __forceinline__ void agg_node_scene_body(const gn_agg_group_t& G, int
       const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 48));
       if (lane == 0) wmax[wave] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)));
     }
+    // (B_w of this type: requested before the barrier, used behind the partner loop)
+    w_fetch(k, offB);
     __syncthreads();
-    // ---- 2. S = sum_j ef relu(A'_n + A'_j): the next type's weights and pair weights are requested first
-    w_fetch(wb, k, offB);
+    // ---- 2. S = sum_j ef relu(A'_n + A'_j) for this workgroup's row block
     const int kn = k + 1 < K ? k + 1 : k;
-    w_fetch(wa, kn, offA);
     ef_fetch(kn);
     const float bf0 = G.b2[k * 64 + r], bf1 = G.b2[k * 64 + 32 + r];
     const u32x4 wm = *reinterpret_cast<const u32x4*>(wmax);
@@ -1186,115 +1195,104 @@ __device__ __forceinline__ void agg_node_scene_body(const gn_agg_group_t& G, int
     const float isc = __builtin_bit_cast(float, (unsigned)(min(eb, 199) + 2) << 23);
     const float* ec = efk + (k & 1) * EP;
     const float* prow = stage + 32 * wave;
+    f32x2 acc2[8];
+    float csum = 0.f;
+    {
+      const PreTile a = load_pre(prow + n * kStagePitch, h);
+      f32x2 as[8];
 #pragma unroll
-    for (int rbI = 0; rbI < 2; ++rbI)
-      if (rbI < RBN) {
-        const int n = min(rbI * 32 + r, N - 1);
-        const PreTile a = load_pre(prow + n * kStagePitch, h);
-        f32x2 as[8], acc2[8];
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            as[2 * q + c] = clamp_form ? f32x2{a.v[q][2 * c] * sc, a.v[q][2 * c + 1] * sc} : f32x2{a.v[q][2 * c], a.v[q][2 * c + 1]};
-            acc2[2 * q + c] = f32x2{0.f, 0.f};
-          }
-        float csum = 0.f;
-        const f32x2 s2 = {sc, sc};
-        auto accumulate = [&](const PreTile& pb, float e) {
-          if (clamp_form) {
-            const float es = e * isc;
-            const f32x2 e2 = {es, es};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-              for (int c = 0; c < 2; ++c) {
-                const f32x2 rl = pk_fma_clamp(f32x2{pb.v[q][2 * c], pb.v[q][2 * c + 1]}, s2, as[2 * q + c]);
-                acc2[2 * q + c] = __builtin_elementwise_fma(e2, rl, acc2[2 * q + c]);
-              }
-          } else {
-            const f32x2 e2 = {e, e};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-              for (int c = 0; c < 2; ++c) {
-                const f32x2 t2 = as[2 * q + c] + f32x2{pb.v[q][2 * c], pb.v[q][2 * c + 1]};
-                const f32x2 m2 = {fmaxf(t2[0], 0.f), fmaxf(t2[1], 0.f)};
-                acc2[2 * q + c] = __builtin_elementwise_fma(e2, m2, acc2[2 * q + c]);
-              }
-          }
-          csum += e;
-        };
-        // partner j: row j of the stage (the same for every lane), weight ef[p(n, j)]; one partner ahead in flight
-        auto wgt = [&](int j) {
-          const int jj = min(j, N - 1);
-          const int fj = jj * (N - 1) - jj * (jj - 1) / 2;
-          return ec[min(fj + n, fn[rbI] + jj)];
-        };
-        PreTile pA = load_pre(prow, h), pB;
-        float eA = wgt(0), eB;
-        int j = 0;
-        for (; j + 1 < N; j += 2) {
-          pB = load_pre(prow + (j + 1) * kStagePitch, h), eB = wgt(j + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          accumulate(pA, eA);
-          pA = load_pre(prow + min(j + 2, N - 1) * kStagePitch, h), eA = wgt(j + 2);
-          __builtin_amdgcn_sched_barrier(0);
-          accumulate(pB, eB);
+        for (int c = 0; c < 2; ++c) {
+          as[2 * q + c] = clamp_form ? f32x2{a.v[q][2 * c] * sc, a.v[q][2 * c + 1] * sc} : f32x2{a.v[q][2 * c], a.v[q][2 * c + 1]};
+          acc2[2 * q + c] = f32x2{0.f, 0.f};
         }
-        if (j < N) accumulate(pA, eA);
-        // ---- 3. layer 2 on S (bf16 operand), this wave's hidden tile; wave 0 adds b2k c[n, k]
-        f32x16 acc;
+      const f32x2 s2 = {sc, sc};
+      // partner j: row j of the stage (the same for every lane), weight ef[p(n, j)]
+      auto partner = [&](int j, auto clamped) {
+        const PreTile pb = load_pre(prow + j * kStagePitch, h);
+        const int fj = j * (N - 1) - j * (j - 1) / 2;
+        const float e = ec[min(fj + n, fn + j)];
+        csum += e;
+        if constexpr (decltype(clamped)::value) {
+          const float es = e * isc;
+          const f32x2 e2 = {es, es};
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          acc[2 * q] = acc2[q][0];
-          acc[2 * q + 1] = acc2[q][1];
-        }
-        Parts<P> xh[2];
-        make_parts<P>(acc, 0, xh[0], ovf_unused);
-        make_parts<P>(acc, 1, xh[1], ovf_unused);
+          for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) mfma_substep<P>(wb[u], xh[u & 1], out[rbI][u >> 1]);
-        if (wave == 0) {
-          const float cs = h == 0 ? csum : 0.f;
-          out[rbI][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? bf0 : 0.f, cs, out[rbI][0], 0, 0, 0);
-          out[rbI][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? bf1 : 0.f, cs, out[rbI][1], 0, 0, 0);
+            for (int c = 0; c < 2; ++c) {
+              const f32x2 rl = pk_fma_clamp(f32x2{pb.v[q][2 * c], pb.v[q][2 * c + 1]}, s2, as[2 * q + c]);
+              acc2[2 * q + c] = __builtin_elementwise_fma(e2, rl, acc2[2 * q + c]);
+            }
+        } else {
+          const f32x2 e2 = {e, e};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const f32x2 t2 = as[2 * q + c] + f32x2{pb.v[q][2 * c], pb.v[q][2 * c + 1]};
+              const f32x2 m2 = {fmaxf(t2[0], 0.f), fmaxf(t2[1], 0.f)};
+              acc2[2 * q + c] = __builtin_elementwise_fma(e2, m2, acc2[2 * q + c]);
+            }
         }
+      };
+      // (no explicit software pipeline: with GN_SCENE_OCC waves per SIMD the other waves cover a partner's LDS round trip)
+      if (clamp_form) {
+#pragma unroll 2
+        for (int j = 0; j < N; ++j) partner(j, std::integral_constant<bool, true>{});
+      } else {
+#pragma unroll 2
+        for (int j = 0; j < N; ++j) partner(j, std::integral_constant<bool, false>{});
       }
-    __syncthreads();                                   // every wave is past its reads of the stage and of efk[k & 1]
-  }
-  // partial outputs of the four waves meet in LDS (the stage), row block by row block; wave w finishes quads 2w, 2w + 1
-  f32x4* lds = reinterpret_cast<f32x4*>(stage);
-#pragma unroll
-  for (int rbI = 0; rbI < 2; ++rbI)
-    if (rbI < RBN) {
+    }
+    // ---- 3. layer 2 on S (bf16 operand), this wave's hidden tile; wave 0 adds b2k c[n, k]
+    {
+      f32x16 acc;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const f32x4 v = {out[rbI][q >> 2][4 * (q & 3) + 0], out[rbI][q >> 2][4 * (q & 3) + 1],
-                         out[rbI][q >> 2][4 * (q & 3) + 2], out[rbI][q >> 2][4 * (q & 3) + 3]};
-        lds[(wave * 8 + q) * 64 + lane] = v;
+        acc[2 * q] = acc2[q][0];
+        acc[2 * q + 1] = acc2[q][1];
       }
-      __syncthreads();
-      const int n = rbI * 32 + r;
-      if (n < N) {
-        T* yrow = reinterpret_cast<T*>(G.feat) + ((size_t)wg * N + n) * GN_FEAT;
+      Parts<P> xh[2];
+      make_parts<P>(acc, 0, xh[0], ovf_unused);
+      make_parts<P>(acc, 1, xh[1], ovf_unused);
 #pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-          const int q = wave * 2 + qq;
-          f32x4 v = lds[(0 * 8 + q) * 64 + lane];
-#pragma unroll
-          for (int ww = 1; ww < 4; ++ww) {
-            const f32x4 t = lds[(ww * 8 + q) * 64 + lane];
-            v[0] += t[0];
-            v[1] += t[1];
-            v[2] += t[2];
-            v[3] += t[3];
-          }
-          st4(yrow + 32 * (q >> 2) + 8 * (q & 3) + 4 * h, v);
-        }
+      for (int u = 0; u < 4; ++u) mfma_substep<P>(w[u], xh[u & 1], out[u >> 1]);
+      if (wave == 0) {
+        const float cs = h == 0 ? csum : 0.f;
+        out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? bf0 : 0.f, cs, out[0], 0, 0, 0);
+        out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? bf1 : 0.f, cs, out[1], 0, 0, 0);
       }
-      __syncthreads();
     }
+    w_fetch(kn, offA);                                 // A_w of the next type
+    __syncthreads();                                   // every wave is past its reads of the stage and of efk[k & 1]
+  }
+  // partial outputs of the four waves meet in LDS; wave w finishes quads 2w, 2w + 1
+  f32x4* lds = reinterpret_cast<f32x4*>(dyn);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 v = {out[q >> 2][4 * (q & 3) + 0], out[q >> 2][4 * (q & 3) + 1], out[q >> 2][4 * (q & 3) + 2],
+                     out[q >> 2][4 * (q & 3) + 3]};
+    lds[(wave * 8 + q) * 64 + lane] = v;
+  }
+  __syncthreads();
+  if (rbI * 32 + r < N) {
+    T* yrow = reinterpret_cast<T*>(G.feat) + ((size_t)scene * N + rbI * 32 + r) * GN_FEAT;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int q = wave * 2 + qq;
+      f32x4 v = lds[(0 * 8 + q) * 64 + lane];
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) {
+        const f32x4 t = lds[(ww * 8 + q) * 64 + lane];
+        v[0] += t[0];
+        v[1] += t[1];
+        v[2] += t[2];
+        v[3] += t[3];
+      }
+      st4(yrow + 32 * (q >> 2) + 8 * (q & 3) + 4 * h, v);
+    }
+  }
 }
 
 template <int P, typename T>
@@ -1305,9 +1303,8 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
   // wave per row block without the stage (the large bf16 configurations) passes 0 bytes and fits more workgroups per CU.
   extern __shared__ __align__(16) float part_dyn[];
   float (*part)[32][64 + 8] = reinterpret_cast<float (*)[32][64 + 8]>(part_dyn);
-  int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
+  const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
   if (lwg < 0) return;
-  if (Tb.mix_C > 0) lwg = gn_uniform(gn_mix_unmap(lwg, Tb.mix_C, Tb.mix_W0, Tb.mix_Wr));
   const int gi = find_group(Tb, lwg);
   const gn_agg_group_t G = Tb.g[gi].a;
   const int wpr = Tb.g[gi].wpr;
@@ -1352,12 +1349,6 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
   // (the weight image of this group's form and its flag word)
   const void* img = pair_form ? pick_image<P>(G.W2x, G.W2h) : pick_image<P>(G.W12x, G.W12h);
   if constexpr (P == 2) ovf.wf |= image_flag(img, pair_form ? K * 16 : K * 32);
-  if constexpr (P == 1) {
-    if (G.node_form) {                   // (block-uniform: one scene per workgroup)
-      agg_node_scene_body<T>(G, wg, wave, threadIdx.x & 63, part_dyn);
-      return;
-    }
-  }
   if constexpr (P != 1) {
     if (pair_form && G.node_form) {      // (block-uniform; the workgroup's four waves share one 32-node row block)
       agg_node_body<P, T>(G, wg, wave, threadIdx.x & 63, img, reinterpret_cast<float*>(wring), part_dyn, ovf, lwg * 4 + wave);
@@ -1687,18 +1678,13 @@ __global__ __launch_bounds__(256, 2) void agg_rb2_kernel(GroupTable<AggGroup> Tb
   ovf_t ovf_unused = {0ull, 0};      // (the range vote belongs to the two-part fp16 path)
   __shared__ f32x4 wring[WS::kRingF4];
   extern __shared__ __align__(16) unsigned char ori_dyn[];      // staged ori rows of the pairwise gather
-  int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
+  const int lwg = gn_uniform(gn_xcd_logical(Tb.xs, blockIdx.x));
   if (lwg < 0) return;
-  if (Tb.mix_C > 0) lwg = gn_uniform(gn_mix_unmap(lwg, Tb.mix_C, Tb.mix_W0, Tb.mix_Wr));
   const int gi = find_group(Tb, lwg);
   const gn_agg_group_t G = Tb.g[gi].a;
   const int rows = G.rows, K = G.K;
   const int wave = wave_id();
   const int lane = threadIdx.x & 63, h = lane >> 5;
-  if (G.node_form) {                     // (block-uniform: one scene per workgroup)
-    agg_node_scene_body<T>(G, lwg - Tb.first_wg[gi], wave, lane, reinterpret_cast<float*>(ori_dyn));
-    return;
-  }
   const int blk0 = ((lwg - Tb.first_wg[gi]) * 4 + wave) * RB;
   RowBlock rb[RB];
 #pragma unroll

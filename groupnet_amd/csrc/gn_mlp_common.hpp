@@ -114,34 +114,9 @@ struct GroupTable {
   int first_wg[GN_MAX_GROUPS + 1];
   int n;
   XcdSections xs;     // bf16-core kernels: XCD-aware order of the logical workgroups (sections = groups)
-  // Mixed dispatch (typed aggregation of the twins): group 0 is VALU-bound (scene form), the others run on the matrix
-  // cores; dealt in table order a CU would hold two workgroups of the same kind.  With mix_C > 0 the launch order is
-  // mix_C alternating chunks [group 0 chunk i][rest chunk i] (the sections of `xs` are those chunks) and gn_mix_unmap
-  // turns a position in that order into the logical workgroup index.
-  int mix_C, mix_W0, mix_Wr;
 };
-__host__ __device__ __forceinline__ int gn_mix_unmap(int v, int C, int W0, int Wr) {
-  int i = 0;
-  while (i + 1 < C && v >= (int)(((long long)(i + 1) * W0) / C) + (int)(((long long)(i + 1) * Wr) / C)) ++i;
-  const int n0 = (int)(((long long)i * W0) / C), n1 = (int)(((long long)(i + 1) * W0) / C);
-  const int h0 = (int)(((long long)i * Wr) / C);
-  const int off = v - (n0 + h0);
-  return off < n1 - n0 ? n0 + off : W0 + h0 + (off - (n1 - n0));
-}
-// sections = the groups of a table; returns the grid size
 template <typename G>
 inline int table_xcd_grid(GroupTable<G>& T) {
-  if (T.mix_C > 0) {      // sections = the alternating chunks of the mixed order
-    T.xs.n = 2 * T.mix_C;
-    for (int i = 0; i < T.mix_C; ++i) {
-      const int n0 = (int)(((long long)i * T.mix_W0) / T.mix_C), n1 = (int)(((long long)(i + 1) * T.mix_W0) / T.mix_C);
-      const int h0 = (int)(((long long)i * T.mix_Wr) / T.mix_C);
-      T.xs.first[2 * i] = n0 + h0;
-      T.xs.first[2 * i + 1] = n1 + h0;
-    }
-    T.xs.first[2 * T.mix_C] = T.mix_W0 + T.mix_Wr;
-    return gn_xcd_grid(T.xs);
-  }
   T.xs.n = T.n;
   for (int g = 0; g <= T.n; ++g) T.xs.first[g] = T.first_wg[g];
   return gn_xcd_grid(T.xs);

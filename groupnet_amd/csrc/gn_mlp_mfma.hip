@@ -1110,24 +1110,34 @@ extern "C" int gn_edge_mlp_gumbel_bf16(const gn_edge_group_t* groups, int n_grou
 }
 
 // ---- typed aggregation MLP ---------------------------------------------------------------------------------------
-// twins: a scene-form (node form) group leads the table (its cost sorts it first); interleave its workgroups with the
-// matrix-core groups' in launch order (GroupTable::mix_*).  GN_AGG_MIX = 0 keeps table order.
-static void set_mix(GroupTable<AggGroup>& T, int n_groups) {
-  T.mix_C = 0;
-  if (n_groups < 2 || !T.g[0].a.node_form || T.g[0].a.A != nullptr) return;
-  for (int g = 1; g < n_groups; ++g)
-    if (T.g[g].a.node_form) return;
-  // (measured at config 4: 332 us interleaved against 286 us in table order — the scene-form workgroups, the launch's
-  // long pole, slow down beside matrix-core workgroups more than the overlap gains: opt-in, GN_AGG_MIX = 1)
-  const char* e = getenv("GN_AGG_MIX");
-  if (e == nullptr || atoi(e) == 0) return;
-  T.mix_W0 = T.first_wg[1];
-  T.mix_Wr = T.first_wg[n_groups] - T.first_wg[1];
-  if (T.mix_W0 < 64 || T.mix_Wr < 64) return;
-  T.mix_C = 16;
-}
-static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t stream, bool twin) {
-  GN_CHECK(check_groups(groups, n_groups));
+static int agg_launch(const gn_agg_group_t* groups_in, int n_groups_in, hipStream_t stream, bool twin) {
+  GN_CHECK(check_groups(groups_in, n_groups_in));
+  // twins: scene-form groups (node form without A) run in their own kernel (agg_scene_kernel: VALU-bound, compiled for
+  // more waves per SIMD than the matrix-core kernels), ahead of the launch of the remaining groups
+  gn_agg_group_t rest[GN_MAX_GROUPS];
+  int n_groups = 0;
+  for (int g = 0; g < n_groups_in; ++g) {
+    const gn_agg_group_t& G = groups_in[g];
+    if (!(G.node_form && G.A == nullptr)) {
+      rest[n_groups++] = G;
+      continue;
+    }
+    if (!twin || G.eo != nullptr || G.H != nullptr || !G.sym || G.N <= 0 || G.N > 64 || G.E != gn_pair_count(G.N) ||
+        G.rows <= 0 || G.rows % G.E != 0 || G.K < 1 || G.K > GN_MAX_TYPES)
+      return GN_ERR_SHAPE;
+    GN_CHECK(need(G.ori, true));
+    GN_CHECK(need(G.W12x, true));
+    GN_CHECK(need(G.b1, true));
+    GN_CHECK(need(G.b2, false));
+    GN_CHECK(need(G.edge_feat, false));
+    GN_CHECK(need(G.feat, true));
+    const int B = G.rows / G.E, RBN = (G.N + 31) / 32;
+    hipLaunchKernelGGL((agg_scene_kernel<__bf16>), dim3(B * RBN), dim3(256), (size_t)node_scene_lds_floats(G.N) * sizeof(float),
+                       stream, G);
+    GN_CHECK(gn_check_launch());
+  }
+  if (n_groups == 0) return GN_OK;
+  const gn_agg_group_t* groups = rest;
   const int xm = x_mode(groups, n_groups, [](const gn_agg_group_t& G) {
     return (G.A != nullptr ? G.W2x : G.W12x) != nullptr;
   });
@@ -1144,11 +1154,7 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
       // node form: layer 2 per node (bf16-core images only; the type weights of a row block fit the weight ring's LDS)
       if (G.node_form && (!xm || G.N > 16 || G.K > 12)) return GN_ERR_SHAPE;
     } else if (G.node_form) {
-      // twins: node form with both layers per node, one scene per workgroup (pairwise graph, unordered pairs, N <= 64)
-      if (!twin || G.eo != nullptr || G.H != nullptr || !G.sym || G.N <= 0 || G.N > 64 ||
-          G.E != gn_pair_count(G.N) || G.rows % G.E != 0)
-        return GN_ERR_SHAPE;
-      GN_CHECK(need(G.ori, true));
+      return GN_ERR_SHAPE;
     } else if (G.eo != nullptr) {
       GN_CHECK(need(G.eo, true));
     } else {
@@ -1185,9 +1191,8 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
   // (types x layers per wave), so the long waves start first and the short ones fill the tail.
   const bool as_given = getenv("GN_AGG_ORDER_AS_GIVEN") != nullptr;
   if (!as_given) {
-    auto cost = [](const AggGroup& a) {      // (scene-form workgroups walk N partners per node and type: the longest)
-      if (a.a.node_form && a.a.A == nullptr && getenv("GN_AGG_SCENE_LAST") != nullptr) return 0ll;      // (diagnostic)
-      return a.a.node_form ? (a.a.A != nullptr ? 1ll : 1000ll) : (long long)a.a.K * (a.a.A != nullptr ? 1 : 2) * 4 / a.wpr;
+    auto cost = [](const AggGroup& a) {
+      return a.a.node_form ? 1ll : (long long)a.a.K * (a.a.A != nullptr ? 1 : 2) * 4 / a.wpr;
     };
     for (int i = 1; i < n_groups; ++i)        // insertion sort, stable, n <= GN_MAX_GROUPS
       for (int j = i; j > 0 && cost(T.g[j]) > cost(T.g[j - 1]); --j) {
@@ -1199,8 +1204,7 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
   for (int g = 0; g < n_groups; ++g) {
     T.first_wg[g] = wg;
     const gn_agg_group_t& a = T.g[g].a;
-    wg += a.node_form ? (a.A != nullptr ? (a.rows / a.E * a.N + 31) / 32      // one workgroup per 32-NODE row block
-                                        : a.rows / a.E)                        // twins: one workgroup per scene
+    wg += a.node_form ? (a.rows / a.E * a.N + 31) / 32      // one workgroup per 32-NODE row block
                       : ((a.rows + 31) / 32 * T.g[g].wpr + 3) / 4;
   }
   T.first_wg[n_groups] = wg;
@@ -1209,22 +1213,14 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
     // (pairs of row blocks must still fill the chip: >= 2048 waves in all.  GN_AGG_RB2 = 0 / 1 forces the choice —
     // the parity tests run small cases through both kernels)
     long long pairs = 0;
-    size_t scene_need = 0;      // dynamic LDS of the scene-form (node form) groups
-    for (int g = 0; g < n_groups; ++g) {
-      if (groups[g].node_form) {
-        const size_t b = (size_t)node_scene_lds_floats(groups[g].N) * sizeof(float);
-        scene_need = b > scene_need ? b : scene_need;
-      } else {
-        pairs += ((groups[g].rows + 31) / 32 + 1) / 2;
-      }
-    }
+    for (int g = 0; g < n_groups; ++g) pairs += ((groups[g].rows + 31) / 32 + 1) / 2;
     bool rb2 = pairs >= rb2_min_pairs();
     if (const char* e = getenv("GN_AGG_RB2")) rb2 = atoi(e) != 0;
     if (rb2) {
       wg = 0;
       for (int g = 0; g < n_groups; ++g) {
         T.first_wg[g] = wg;
-        wg += T.g[g].a.node_form ? T.g[g].a.rows / T.g[g].a.E : ((T.g[g].a.rows + 31) / 32 + 7) / 8;
+        wg += ((T.g[g].a.rows + 31) / 32 + 7) / 8;
       }
       T.first_wg[n_groups] = wg;
       // LDS for the staged ori rows of the pairwise gather (GN_POOL_STAGE = 0 switches it off)
@@ -1236,8 +1232,6 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
         const size_t b = (size_t)pool_stage_nodes(256, a.E, a.N) * PoolStage<__bf16>::kPitch * sizeof(__bf16);
         if (b <= 48 * 1024 && b > sb) sb = b;
       }
-      if (scene_need > sb) sb = scene_need;      // (the ori stage only asks whether it FITS stage_bytes)
-      set_mix(T, n_groups);
       hipLaunchKernelGGL((agg_rb2_kernel<__bf16>), dim3(table_xcd_grid(T)), dim3(256), sb, stream, T, (int)sb);
       return gn_check_launch();
     }
@@ -1264,17 +1258,14 @@ static int agg_launch(const gn_agg_group_t* groups, int n_groups, hipStream_t st
   for (int g = 0; g < n_groups; ++g) {
     need_part = need_part || T.g[g].wpr > 1 || T.g[g].stage != 0 || T.g[g].lines != 0;
     if (T.g[g].a.node_form) {   // second stage buffer of the row block's scenes + the block's type weights / scene form
-      const size_t b = (T.g[g].a.A != nullptr ? (size_t)node_form_lds_floats(T.g[g].a.N, T.g[g].a.K)
-                                              : (size_t)node_scene_lds_floats(T.g[g].a.N)) * sizeof(float);
+      const size_t b = (size_t)node_form_lds_floats(T.g[g].a.N, T.g[g].a.K) * sizeof(float);
       need_part = true;
       stage_need = b > stage_need ? b : stage_need;
     }
   }
   const size_t part_bytes = need_part ? (stage_need > kAggPartBytes ? stage_need : (size_t)kAggPartBytes) : 0;
-  if (twin) {
-    set_mix(T, n_groups);
+  if (twin)
     hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
-  }
   else if (xm) {
     const int hm = x_mode(groups, n_groups, [](const gn_agg_group_t& G) {
       return (G.A != nullptr ? G.W2h : G.W12h) != nullptr;

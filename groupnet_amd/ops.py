@@ -949,6 +949,9 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
                       + B * N * N * K * 128 * 3)
         else:
             flops += B * E * K * ((2 * 128 * 64 + 2 * 64) + (0 if wkey == "W2t" else 2 * 64 * 128))
+    # (the scene-form groups of the twins run in their own kernel ahead of the others' launch, on the same stream: forked
+    # onto a side stream beside it they were measured at config 4 — single-stream 0.791 -> 0.784 ms, but 4-stream
+    # throughput 1.445 -> 1.338 M scenes/s — and the fork was not kept)
     with torch.cuda.device(dev0), _Probed("agg_mlp_kernel", flops):
         check(_fn("gn_agg_mlp", dt)(arr, len(items), stream_handle()), "gn_agg_mlp")
     return outs

@@ -43,7 +43,7 @@ void run(const char* name, int per_iter, int blocks) {
   hipFree(out); hipFree(cyc);
 }
 int main() {
-  for (int blocks : {256, 512}) {
+  for (int blocks : {256, 512, 1024, 2048}) {
     run<0>("v_fma_f32", 16, blocks); run<1>("v_max_f32", 16, blocks); run<2>("v_pk_add_f32", 8, blocks); run<3>("v_pk_fma_f32", 8, blocks);
     run<4>("v_pk_fma_f32 op_sel_hi", 8, blocks); run<5>("v_pk_fma_f32 clamp", 8, blocks); run<6>("v_pk_mul_f32", 8, blocks);
   }
