@@ -146,9 +146,12 @@ def _himg(pk: dict, name: str, dtype: torch.dtype) -> int:
 
 
 class _Probed:
+    """flops: the EXECUTED fp32-equivalent count of the launch, or (executed, reference form) where a stage runs an
+    algebraically reduced form (typed aggregation: the reference form is every ordered edge through both layers,
+    SURVEY.md 8d)."""
     __slots__ = ("name", "flops", "probe")
 
-    def __init__(self, name: str, flops: int):
+    def __init__(self, name: str, flops):
         self.name, self.flops, self.probe = name, flops, launch_probe
 
     def __enter__(self):
@@ -901,7 +904,7 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
     _groups(len(items))
     arr = (_lib.AggGroup * len(items))()
     outs = []
-    flops = 0
+    flops = ref_flops = 0
     dev0 = dt = None
     for g, (eo, edge_feat, pk, K) in enumerate(items):
         wkey = "W"
@@ -949,6 +952,11 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
                       + B * N * N * K * 128 * 3)
         else:
             flops += B * E * K * ((2 * 128 * 64 + 2 * 64) + (0 if wkey == "W2t" else 2 * 64 * 128))
+        # the reference's form of the stage (model/MS_HGNN_batch.py:262-265): every edge row — all N*N ordered edges of
+        # the pairwise graph — through both layers of every type
+        pairwise = isinstance(eo, PairSpec) or (isinstance(eo, GatherSpec) and eo.H is None)
+        ref_flops += B * (N * N if pairwise else E) * K * (2 * 64 * 128 + 2 * 128 * 64 + 2 * 64)
+    flops = (flops, ref_flops)
     # (the scene-form groups of the twins run in their own kernel ahead of the others' launch, on the same stream: forked
     # onto a side stream beside it they were measured at config 4 — single-stream 0.791 -> 0.784 ms, but 4-stream
     # throughput 1.445 -> 1.338 M scenes/s — and the fork was not kept)

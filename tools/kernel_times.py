@@ -32,7 +32,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     ov = bench.empty_bracket_ms()
     tot = 0.0
-    for k, (ms, fl, n) in probe.summary(ov).items():
+    for k, (ms, fl, n, _ref) in probe.summary(ov).items():
         print(f"{k:28s} {ms*1e3:8.2f} us  {fl/(ms*1e-3)/1e12:8.1f} TFLOP/s")
         tot += ms
     print(f"sum of probed kernels {tot*1e3:.1f} us")
