@@ -554,6 +554,10 @@ class _MessagePassing(nn.Module):
         return MSHGNNFunction.apply((self,), (H,), (noise_u,), h, *_plist(self))
 
 
+class _Closed(list):
+    """Outputs of closing MLPs that the aggregation launch applied itself."""
+
+
 def _pair_form() -> bool:
     """Pairwise module, fp32 entry points: first layer of the typed aggregation MLP per NODE in the node stage + pair
     form (True), or both layers per unordered pair inside the aggregation kernel (False: no `A` tensor)."""
@@ -645,7 +649,10 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
                 t.estage.append(kd)
         return res
 
-    def edge2node(edge_feats: Sequence[Tensor], oris: Sequence[Tensor], idx: int) -> List[Tensor]:
+    def edge2node(edge_feats: Sequence[Tensor], oris: Sequence[Tensor], idx: int, closing=None) -> List[Tensor]:
+        """-> the inputs of the stage's closing MLPs (tensors / ScatterSpec / NodeAggSpec); with ``closing`` = [(packed
+        MLP, out or None)] per module and a launch shape that allows it, the closing MLPs' OUTPUTS (the aggregation launch
+        applies them itself) as a `_Closed` list."""
         aggs = [m.edge_aggregation_list[idx] for m in mods]
         items = []
         # larger graphs: eo = H @ ori of every hyper module from ONE stand-alone gather launch
@@ -668,6 +675,10 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
             else:
                 src = eos[i]
             items.append((src, edge_feats[i], pk, K))
+        if (closing is not None and traces is None and not twin and N <= _FUSED_SCATTER_MAX_N
+                and len({(-1 if o is None else o.stride(-2)) for _, o in closing}) == 1
+                and ops.closing_fusable(items, [pk2 for pk2, _ in closing])):
+            return _Closed(ops.agg_mlp_grouped(items, [(pk2, o, ori) for (pk2, o), ori in zip(closing, oris)]))
         feats = ops.agg_mlp_grouped(items)
 
         def node_item(it) -> bool:
@@ -691,9 +702,10 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
     for l in range(2 * (nmp - 1)):
         stages = [m.nmp_mlps[l] for m in mods]
         if l % 2 == 0:
-            agg = edge2node(edge_feats, node_feats, idx)
+            agg = edge2node(edge_feats, node_feats, idx, [(m._packed_mlp2(st), None) for m, st in zip(mods, stages)])
             keep = [] if traces is not None else None
-            node_feats = ops.mlp2_grouped([(a, m._packed_mlp2(st), None) for a, m, st in zip(agg, mods, stages)], keep)
+            node_feats = (list(agg) if isinstance(agg, _Closed) else
+                          ops.mlp2_grouped([(a, m._packed_mlp2(st), None) for a, m, st in zip(agg, mods, stages)], keep))
             idx += 1
             if traces is not None:
                 for t, x, kd in zip(traces, node_feats, keep):
@@ -705,7 +717,9 @@ def run_message_passing(mods: Sequence["_MessagePassing"], hs: Sequence[Tensor],
             if traces is not None:
                 for t, r in zip(traces, res):
                     t.dists.append(r[1])
-    agg = edge2node(edge_feats, node_feats, idx)
+    agg = edge2node(edge_feats, node_feats, idx, [(m._packed_mlp2(m.nmp_mlp_end), o) for m, o in zip(mods, outs)])
+    if isinstance(agg, _Closed):
+        return list(zip(list(agg), factors))
     ends = [(a, m._packed_mlp2(m.nmp_mlp_end), o) for a, m, o in zip(agg, mods, outs)]
     # the last MLP writes in place when `out` is given; grouped when every group has the same stride
     strides = {(-1 if o is None else o.stride(-2)) for o in outs}

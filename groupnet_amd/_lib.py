@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the .so is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GROUPNET_HIP_LIB") or os.path.join(_HERE, "libgroupnet_hip.so")  # env: tuning builds
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 GN_OK = 0
 GN_ERR_K_RANGE = -3
@@ -48,7 +48,8 @@ class GatherGroup(ctypes.Structure):    # gn_gather_group_t
 class AggGroup(ctypes.Structure):       # gn_agg_group_t
     _fields_ = [("eo", _P), ("edge_feat", _P), ("W", _P), ("b1", _P), ("b2", _P), ("feat", _P), ("rows", _I),
                 ("K", _I), ("ori", _P), ("H", _P), ("E", _I), ("N", _I), ("sym", _I), ("A", _P), ("W2x", _P), ("W12x", _P),
-                ("W2h", _P), ("W12h", _P), ("node_form", _I)]
+                ("W2h", _P), ("W12h", _P), ("node_form", _I), ("m2x", _P), ("m2h", _P), ("m2bias", _P), ("y", _P), ("ldy", _I),
+                ("dout", _I), ("divisor", _F)]
 
 
 class ScatterGroup(ctypes.Structure):   # gn_scatter_group_t

@@ -1052,7 +1052,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 256 * 16) 
 
 }  // namespace
 
-extern "C" int gn_abi_version(void) { return 33; }
+extern "C" int gn_abi_version(void) { return 34; }
 
 extern "C" const char* gn_strerror(int code) {
   switch (code) {

@@ -781,10 +781,175 @@ __device__ __forceinline__ void add_b2(const float* __restrict__ b2k, float efk,
 
 constexpr int kAggPartBytes = 4 * 32 * (64 + 8) * 4;
 
+
+// A wave's private walk over L sub-steps whose addresses `at(s)` gives (s a compile-time constant after unrolling):
+// a ring of D sub-steps refilled straight from L2.
+template <int P, int L>
+struct PStream {
+  static constexpr int D = P == 1 ? 8 : 4;
+  f32x4 q[D][P];
+  template <typename AT>
+  __device__ __forceinline__ void begin(AT at) {
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+      if (u < L) {
+        const f32x4* src = at(u);
+#pragma unroll
+        for (int p = 0; p < P; ++p) q[u][p] = src[p * 64];
+      }
+  }
+  template <typename AT>
+  __device__ __forceinline__ void step(int s, AT at, const Parts<P>& x, f32x16& acc) {
+    mfma_substep<P>(q[s % D], x, acc);
+    if (s + D < L) {
+      const f32x4* src = at(s + D);
+#pragma unroll
+      for (int p = 0; p < P; ++p) q[s % D][p] = src[p * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);     // (keeps the run-ahead loads where they are issued)
+  }
+};
+
+
+// operand exchange through LDS: the bf16 part(s) of one input tile, lane-linear 16-byte pieces (conflict-free)
+template <int P>
+__device__ __forceinline__ void put_parts(f32x4* lds, int tile, int lane, const f32x16& v, ovf_t& ovf) {
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    Parts<P> x;
+    make_parts<P>(v, hf, x, ovf);
+#pragma unroll
+    for (int p = 0; p < P; ++p) lds[((tile * 2 + hf) * P + p) * 64 + lane] = __builtin_bit_cast(f32x4, x.p[p]);
+  }
+}
+template <int P, int IT>
+__device__ __forceinline__ void get_parts(const f32x4* lds, int lane, Parts<P> (&xi)[IT][2]) {
+#pragma unroll
+  for (int t = 0; t < IT; ++t)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int p = 0; p < P; ++p) xi[t][hf].p[p] = __builtin_bit_cast(bf16x8, lds[((t * 2 + hf) * P + p) * 64 + lane]);
+}
+// partial output tiles of the 4 waves: [wave][quad of 4 registers][lane] as 16-byte pieces
+template <int OT>
+__device__ __forceinline__ void put_partial(f32x4* lds, int wave, int lane, const f32x16 (&out)[OT]) {
+#pragma unroll
+  for (int q = 0; q < 4 * OT; ++q) {
+    const f32x4 v = {out[q >> 2][4 * (q & 3) + 0], out[q >> 2][4 * (q & 3) + 1], out[q >> 2][4 * (q & 3) + 2],
+                     out[q >> 2][4 * (q & 3) + 3]};
+    lds[(wave * 4 * OT + q) * 64 + lane] = v;
+  }
+}
+template <int OT>
+__device__ __forceinline__ f32x4 sum_partial(const f32x4* lds, int q, int lane) {      // fixed order: ((w0+w1)+w2)+w3
+  f32x4 v = lds[(0 * 4 * OT + q) * 64 + lane];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const f32x4 a = lds[(w * 4 * OT + q) * 64 + lane];
+    v[0] += a[0];
+    v[1] += a[1];
+    v[2] += a[2];
+    v[3] += a[3];
+  }
+  return v;
+}
+
 // sub-step offsets of A_t / B_t inside a pipeline-ordered layer-pair image (A0 A1 B0 A2 B1 ... A(HT-1) B(HT-2) B(HT-1))
 __device__ __forceinline__ int pipe_off_A(int t, int NA, int NB) { return t == 0 ? 0 : NA + (t - 1) * (NA + NB); }
 __device__ __forceinline__ int pipe_off_B(int t, int HT, int NA, int NB) {
   return t < HT - 1 ? 2 * NA + t * (NA + NB) : HT * NA + (HT - 1) * NB;
+}
+
+// ---- the closing MLP (128 -> 128 -> dout, 32 < dout <= 64) of ONE 32-row block by the 4 waves of a workgroup, inputs in LDS
+// What mlp2_xs_body does behind its input-forming prologue, as a function: the typed-aggregation workgroups call it on the
+// node rows whose aggregate they have just finished (gn_agg_group_t.y: the closing stage fused into the aggregation
+// launch).  X: 32 rows x kXPitch floats, cat(H^T feat, ori) / divisor; lds: 32 KiB of exchange space (operand parts, then
+// the partial outputs); every wave of the workgroup calls it with the same arguments.  Same image, same sub-step order,
+// same sums as mlp2_xs_body: bit-identical rows.  (Requesting a wave's 12 sub-steps once per workgroup and keeping them
+// for every row block it closes was measured: 96 / 144 more live registers, 156 bytes of scratch, launch +2 us.)
+constexpr int kXPitch = 128 + 4;
+template <int P, typename T>
+__device__ __forceinline__ void closing_chain(const void* image, const float* __restrict__ bias, T* __restrict__ y, int ldy,
+                                              int dout, int row0, int nlive, const float* __restrict__ X, f32x4* lds,
+                                              int wave, int lane, ovf_t& ovf) {
+  constexpr int IT = 4, HT = 4, OT = 2, NA = 2 * IT, NB = 2 * OT, L = NA + NB;
+  const int h = lane >> 5, r = lane & 31;
+  if constexpr (P == 2) ovf.wf |= image_flag(image, HT * (NA + NB));
+  const f32x4* img = reinterpret_cast<const f32x4*>(image) + lane;
+  const f32x4* segA = img + (size_t)pipe_off_A(wave, NA, NB) * P * 64;
+  const f32x4* segB = img + (size_t)pipe_off_B(wave, HT, NA, NB) * P * 64;
+  auto at = [&](int s) -> const f32x4* { return s < NA ? segA + s * P * 64 : segB + (s - NA) * P * 64; };
+  PStream<P, L> ps;
+  {
+    f32x16 in;                                       // wave w forms the operand parts of input tile w
+    const float* xr = X + r * kXPitch + 32 * wave + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 8 * q);
+      in[4 * q + 0] = v[0], in[4 * q + 1] = v[1], in[4 * q + 2] = v[2], in[4 * q + 3] = v[3];
+    }
+    ps.begin(at);
+    put_parts<P>(lds, wave, lane, in, ovf);
+  }
+  __syncthreads();
+  auto xop = [&](int u, Parts<P>& x) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) x.p[p] = __builtin_bit_cast(bf16x8, lds[(u * P + p) * 64 + lane]);
+  };
+  Parts<P> xa[2];
+  xop(0, xa[0]);
+  const f32x16 bt = load_bias_tile(bias + 32 * wave, h);
+  f32x16 hid;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) hid[q] = 0.f;
+#pragma unroll
+  for (int u = 0; u < NA; ++u) {
+    if (u + 1 < NA) xop(u + 1, xa[(u + 1) & 1]);
+    ps.step(u, at, xa[u & 1], hid);
+  }
+  f32x16 out[OT], bo[OT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o) {
+    if (wave == 0) bo[o] = load_bias_tile(bias + 32 * HT + 32 * o, h);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[o][q] = 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) hid[q] += bt[q];
+  relu16(hid);
+  Parts<P> xh[2];
+  make_parts<P>(hid, 0, xh[0], ovf);
+  make_parts<P>(hid, 1, xh[1], ovf);
+#pragma unroll
+  for (int u = 0; u < NB; ++u) ps.step(NA + u, at, xh[u & 1], out[u >> 1]);
+  if (wave == 0) {
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) out[o][q] += bo[o][q];
+  }
+  __syncthreads();                                   // every wave is past its reads of the exchanged operands
+  put_partial<OT>(lds, wave, lane, out);
+  __syncthreads();
+  if (r < nlive) {
+    T* yrow = y + (size_t)(row0 + r) * ldy;
+    const bool vec = ((dout | ldy) & 3) == 0;
+#pragma unroll
+    for (int qq = 0; qq < OT; ++qq) {                // wave w finishes quads [w*OT, w*OT + OT) of the 4*OT
+      const int q = wave * OT + qq;
+      const f32x4 v = sum_partial<OT>(lds, q, lane);
+      const int f = 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+      if (vec) {
+        if (f < dout) st4(yrow + f, v);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (f + c < dout) st1(yrow + f + c, v[c]);
+      }
+    }
+  }
+  __syncthreads();                                   // (the caller may reuse X / lds)
 }
 
 // ---- node form of the pairwise typed aggregation (gn_agg_group_t.node_form; N <= 16, K <= 12) ----------------------------
@@ -1042,6 +1207,52 @@ __device__ __forceinline__ void agg_node_body(const gn_agg_group_t& G, int wg, i
     lds[(wave * 8 + q) * 64 + lane] = v;
   }
   __syncthreads();
+  if (G.y != nullptr) {
+    // ---- fused closing stage: X = cat(H^T feat, ori) / divisor of the block's 32 nodes in stage buffer 0 (free now),
+    // the chain's exchange space in the dynamic part (behind a barrier: the partial outputs are read from there first)
+    float* X = stage0;
+    f32x4 v2[2];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int q = wave * 2 + qq;
+      f32x4 v = lds[(0 * 8 + q) * 64 + lane];
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) {
+        const f32x4 t = lds[(ww * 8 + q) * 64 + lane];
+        v[0] += t[0];
+        v[1] += t[1];
+        v[2] += t[2];
+        v[3] += t[3];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = v[c] / G.divisor;
+      v2[qq] = v;
+    }
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int q = wave * 2 + qq;
+      *reinterpret_cast<f32x4*>(X + r * kXPitch + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) = v2[qq];
+    }
+    {
+      const int row = (int)threadIdx.x >> 3, piece = (int)threadIdx.x & 7;
+      const T* orow = reinterpret_cast<const T*>(G.ori) + (size_t)min(g0 + row, rowsN - 1) * GN_FEAT + 4 * piece;
+      f32x4 o0 = ld4(orow), o1 = ld4(orow + 32);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        o0[c] = o0[c] / G.divisor;
+        o1[c] = o1[c] / G.divisor;
+      }
+      *reinterpret_cast<f32x4*>(X + row * kXPitch + 64 + 4 * piece) = o0;
+      *reinterpret_cast<f32x4*>(X + row * kXPitch + 96 + 4 * piece) = o1;
+    }
+    __syncthreads();
+    closing_chain<P, T>(pick_image<P>(G.m2x, G.m2h), G.m2bias, reinterpret_cast<T*>(G.y), G.ldy, G.dout, g0,
+                        rowsN - g0, X, reinterpret_cast<f32x4*>(dyn), wave, lane, ovf);
+    GN_STAMP(unit, 3);
+    GN_STAMP(unit, 4);
+    GN_STAMP(unit, 9);
+    return;
+  }
   if (g0 + r < rowsN) {
     T* yrow = reinterpret_cast<T*>(G.feat) + (size_t)(g0 + r) * GN_FEAT;
 #pragma unroll
@@ -1295,7 +1506,10 @@ __global__ __launch_bounds__(256, GN_SCENE_OCC) void agg_scene_kernel(gn_agg_gro
   }
 }
 
-template <int P, typename T>
+// PAIRF: the per-pair forms of the pairwise graph are compiled in.  They are what costs the kernel its last registers (28
+// bytes of scratch per lane); since the node form replaced them in the default path the launcher picks the instantiation
+// without them whenever no group of the launch needs one (fp32 path beyond N = 16, GN_NODE_FORM = 0).
+template <int P, typename T, bool PAIRF>
 __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4* wring, ovf_t& ovf) {
   using WS = WStream<P>;
   constexpr int CH = WS::CH;
@@ -1318,9 +1532,24 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
   //           in LDS.
   const int sub = wave % wpr;
   const int blk = wg * (4 / wpr) + wave / wpr;
-  const bool any_rows = blk * 32 < rows;
   const bool staged = Tb.g[gi].stage != 0;
-  const RowBlock rb = row_block(rows, any_rows ? blk : 0);     // (no early exit: every wave takes part in the barriers)
+  // Fused closing stage of a hyper group (spw > 0): the workgroup's edge rows are the `spw` whole scenes wg*spw ..., so
+  // that it can form H^T feat of those scenes' nodes itself — rows_used = spw * E of its 128 / wpr row slots
+  const int spw = Tb.g[gi].spw;
+  const bool fused = G.y != nullptr;
+  const int rows_used = spw * G.E;
+  bool any_rows_ = blk * 32 < rows;
+  RowBlock rb_ = row_block(rows, any_rows_ ? blk : 0);         // (no early exit: every wave takes part in the barriers)
+  if (fused && !G.node_form) {
+    const int lb = wave / wpr, lr = lb * 32 + (rb_.lane & 31);
+    const int row = wg * rows_used + lr;
+    any_rows_ = lb * 32 < rows_used && wg * rows_used + lb * 32 < rows;
+    rb_.live = lr < rows_used && row < rows;
+    rb_.row = row;
+    rb_.row_ld = rb_.live ? row : min(wg * rows_used + min(lr, rows_used - 1), rows - 1);
+  }
+  const bool any_rows = any_rows_;
+  const RowBlock rb = rb_;
   const int lane = rb.lane, h = rb.h;
   f32x16 out[2];
 #pragma unroll
@@ -1340,12 +1569,15 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
   const bool hstage = Tb.g[gi].lines == 2;
   int hnode0 = 0;
   if (hstage) {
-    const int rpw = 128 / wpr, r0 = min(wg * rpw, rows - 1);
+    const int rpw = fused ? rows_used : 128 / wpr, r0 = min(wg * rpw, rows - 1);
     hnode0 = ori_stage_fill<T>(G, r0, min(rows - 1, r0 + rpw - 1), reinterpret_cast<T*>(part_dyn));
     __syncthreads();
   }
   bool pair_form = false;
   if constexpr (P != 1) pair_form = G.A != nullptr;
+  if constexpr (!PAIRF) {
+    if (pair_form && !G.node_form) return;      // (the launcher never sends such a group here)
+  }
   // (the weight image of this group's form and its flag word)
   const void* img = pair_form ? pick_image<P>(G.W2x, G.W2h) : pick_image<P>(G.W12x, G.W12h);
   if constexpr (P == 2) ovf.wf |= image_flag(img, pair_form ? K * 16 : K * 32);
@@ -1355,7 +1587,7 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
       return;
     }
   }
-  if (pair_form && wpr == 1) {
+  if (PAIRF && pair_form && wpr == 1) {
     // ---- pair form: hid_t = relu(A_i + A_j) * ef_k is VALU work (V_t), its layer-2 slice the matrix work (B_t:
     // one chunk of the stream, 16 sub-steps per type).  wpr == 1, pipelined: V of the NEXT tile (the next type's
     // tile 0 after t == 3) is interleaved with the MFMAs of B_t; the pre-activations it needs were loaded one tile
@@ -1485,7 +1717,7 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
         efk = efk_next;
       }
     }
-  } else if (pair_form) {
+  } else if (PAIRF && pair_form) {
     // ---- pair form, wpr > 1: types dealt over the waves of a row block, private register rings ----------------------
     if (any_rows && sub < K) {
       const int N = G.N, Pn = G.E;
@@ -1634,6 +1866,89 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
     for (int r = 0; r < 16; ++r) part[wave][16 * o + r][lane] = out[o][r];
   __syncthreads();
   // the wpr waves of a row block each finish 32/wpr of its registers
+  if constexpr (P != 1) {
+    if (fused) {
+      // ---- fused closing stage: feat of the workgroup's scenes -> LDS, H^T feat and ori of their nodes -> X, closing MLP
+      // per 32-node row block (closing_chain).  The summed registers first (all reads of `part` done), then `part`'s LDS
+      // is reused: F = feat rows [rows_used][kFPitch], X behind it.
+      constexpr int kFPitch = GN_FEAT + 4;
+      f32x4 fv[8];
+      const int w0 = wave - sub, nreg = 32 / wpr;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u * 4 < nreg) {
+          const int reg0 = sub * nreg + u * 4;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          for (int jw = 0; jw < wpr; ++jw) {
+            v[0] += part[w0 + jw][reg0 + 0][lane];
+            v[1] += part[w0 + jw][reg0 + 1][lane];
+            v[2] += part[w0 + jw][reg0 + 2][lane];
+            v[3] += part[w0 + jw][reg0 + 3][lane];
+          }
+          fv[u] = v;
+        }
+      }
+      __syncthreads();
+      float* F = part_dyn;
+      float* X = part_dyn + 64 * kFPitch;
+      {
+        const int lr = (wave / wpr) * 32 + (lane & 31);
+        if (lr < rows_used) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (u * 4 < nreg) {
+              const int reg0 = sub * nreg + u * 4;
+              const int o = reg0 >> 4, q = (reg0 & 15) >> 2;
+              *reinterpret_cast<f32x4*>(F + lr * kFPitch + 32 * o + 8 * q + 4 * h) = fv[u];
+            }
+        }
+      }
+      __syncthreads();
+      const int N = G.N, E = G.E;
+      const int scene0 = wg * spw, B = rows / E;
+      const int nodes = min(spw, B - scene0) * N;                  // node rows of this workgroup (>= 1)
+      const T* orib = reinterpret_cast<const T*>(G.ori);
+      for (int nb = 0; nb * 32 < nodes; ++nb) {
+        // X[row][0..63] = (sum_e H[b,e,n] feat[b,e]) / divisor in the order of the fused scatter of gn_mlp2 (e ascending,
+        // fmaf), X[row][64..127] = ori[b,n] / divisor; thread (row = t / 8, piece = t % 8) forms two 16-byte pieces of each
+        const int row = (int)threadIdx.x >> 3, piece = (int)threadIdx.x & 7;
+        const int m = min(nb * 32 + row, nodes - 1);               // node of this workgroup (clamped)
+        const int sl = m / N, n = m - sl * N;
+        const float* hcol = G.H + ((size_t)(scene0 + sl) * E) * N + n;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < E; ++e) {
+          const float w = hcol[(size_t)e * N];
+          const float* fr = F + (sl * E + e) * kFPitch + 4 * piece;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(fr), v1 = *reinterpret_cast<const f32x4*>(fr + 32);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            a0[c] = fmaf(w, v0[c], a0[c]);
+            a1[c] = fmaf(w, v1[c], a1[c]);
+          }
+        }
+        const T* orow = orib + ((size_t)scene0 * N + m) * GN_FEAT + 4 * piece;
+        f32x4 o0 = ld4(orow), o1 = ld4(orow + 32);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          a0[c] = a0[c] / G.divisor;
+          a1[c] = a1[c] / G.divisor;
+          o0[c] = o0[c] / G.divisor;
+          o1[c] = o1[c] / G.divisor;
+        }
+        float* xr = X + row * kXPitch + 4 * piece;
+        *reinterpret_cast<f32x4*>(xr) = a0;
+        *reinterpret_cast<f32x4*>(xr + 32) = a1;
+        *reinterpret_cast<f32x4*>(xr + 64) = o0;
+        *reinterpret_cast<f32x4*>(xr + 96) = o1;
+        __syncthreads();
+        closing_chain<P, T>(pick_image<P>(G.m2x, G.m2h), G.m2bias, reinterpret_cast<T*>(G.y), G.ldy, G.dout,
+                            scene0 * N + nb * 32, nodes - nb * 32, X, wring, wave, lane, ovf);
+      }
+      GN_STAMP(unit, 4);
+      GN_STAMP(unit, 9);
+      return;
+    }
+  }
   if (rb.live && any_rows) {
     T* p = feat + (size_t)rb.row * GN_FEAT + 4 * h;
     const int w0 = wave - sub;
@@ -1654,10 +1969,10 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
   GN_STAMP(unit, 4);
   GN_STAMP(unit, 9);
 }
-template <int P, typename T>
+template <int P, typename T, bool PAIRF>
 __global__ __launch_bounds__(256, P == 1 ? GN_OCC_P1 : 2) void agg_x_kernel(GroupTable<AggGroup> Tb) {
   __shared__ f32x4 wring[kRingF4For<P>];
-  run_with_fallback<P>([&](auto pc, ovf_t& ovf) { agg_x_body<decltype(pc)::value, T>(Tb, wring, ovf); });
+  run_with_fallback<P>([&](auto pc, ovf_t& ovf) { agg_x_body<decltype(pc)::value, T, PAIRF>(Tb, wring, ovf); });
 }
 
 // ---- A5 typed MLP, bf16 storage, TWO row blocks per wave (large launches, one wave per row-block pair) --------------
@@ -2136,35 +2451,6 @@ __global__ __launch_bounds__(256, P == 1 ? (IT == 4 ? 2 : 3) : (IT == 4 ? 1 : 2)
 // critical path is its 132 long "A" workgroups, not the chain.
 // =====================================================================================================================
 
-// A wave's private walk over L sub-steps whose addresses `at(s)` gives (s a compile-time constant after unrolling):
-// a ring of D sub-steps refilled straight from L2.
-template <int P, int L>
-struct PStream {
-  static constexpr int D = P == 1 ? 8 : 4;
-  f32x4 q[D][P];
-  template <typename AT>
-  __device__ __forceinline__ void begin(AT at) {
-#pragma unroll
-    for (int u = 0; u < D; ++u)
-      if (u < L) {
-        const f32x4* src = at(u);
-#pragma unroll
-        for (int p = 0; p < P; ++p) q[u][p] = src[p * 64];
-      }
-  }
-  template <typename AT>
-  __device__ __forceinline__ void step(int s, AT at, const Parts<P>& x, f32x16& acc) {
-    mfma_substep<P>(q[s % D], x, acc);
-    if (s + D < L) {
-      const f32x4* src = at(s + D);
-#pragma unroll
-      for (int p = 0; p < P; ++p) q[s % D][p] = src[p * 64];
-    }
-    __builtin_amdgcn_sched_barrier(0);     // (keeps the run-ahead loads where they are issued)
-  }
-};
-
-
 template <typename T>
 __device__ __forceinline__ void add_row_tile(const T* __restrict__ src, float w, int h, f32x16& a) {   // src: row + 32*tile
   const T* p = src + 4 * h;
@@ -2309,50 +2595,6 @@ __device__ __forceinline__ void read_tile_lines(const float* __restrict__ scratc
     in[4 * q + 2] = v[2];
     in[4 * q + 3] = v[3];
   }
-}
-
-// operand exchange through LDS: the bf16 part(s) of one input tile, lane-linear 16-byte pieces (conflict-free)
-template <int P>
-__device__ __forceinline__ void put_parts(f32x4* lds, int tile, int lane, const f32x16& v, ovf_t& ovf) {
-#pragma unroll
-  for (int hf = 0; hf < 2; ++hf) {
-    Parts<P> x;
-    make_parts<P>(v, hf, x, ovf);
-#pragma unroll
-    for (int p = 0; p < P; ++p) lds[((tile * 2 + hf) * P + p) * 64 + lane] = __builtin_bit_cast(f32x4, x.p[p]);
-  }
-}
-template <int P, int IT>
-__device__ __forceinline__ void get_parts(const f32x4* lds, int lane, Parts<P> (&xi)[IT][2]) {
-#pragma unroll
-  for (int t = 0; t < IT; ++t)
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int p = 0; p < P; ++p) xi[t][hf].p[p] = __builtin_bit_cast(bf16x8, lds[((t * 2 + hf) * P + p) * 64 + lane]);
-}
-// partial output tiles of the 4 waves: [wave][quad of 4 registers][lane] as 16-byte pieces
-template <int OT>
-__device__ __forceinline__ void put_partial(f32x4* lds, int wave, int lane, const f32x16 (&out)[OT]) {
-#pragma unroll
-  for (int q = 0; q < 4 * OT; ++q) {
-    const f32x4 v = {out[q >> 2][4 * (q & 3) + 0], out[q >> 2][4 * (q & 3) + 1], out[q >> 2][4 * (q & 3) + 2],
-                     out[q >> 2][4 * (q & 3) + 3]};
-    lds[(wave * 4 * OT + q) * 64 + lane] = v;
-  }
-}
-template <int OT>
-__device__ __forceinline__ f32x4 sum_partial(const f32x4* lds, int q, int lane) {      // fixed order: ((w0+w1)+w2)+w3
-  f32x4 v = lds[(0 * 4 * OT + q) * 64 + lane];
-#pragma unroll
-  for (int w = 1; w < 4; ++w) {
-    const f32x4 a = lds[(w * 4 * OT + q) * 64 + lane];
-    v[0] += a[0];
-    v[1] += a[1];
-    v[2] += a[2];
-    v[3] += a[3];
-  }
-  return v;
 }
 
 // ---- closing MLP, 4 waves per row block: y = W1 relu(W0 x + b0) + b1, dout <= 64 ----------------------------------------

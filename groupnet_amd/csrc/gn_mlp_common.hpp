@@ -746,6 +746,7 @@ struct AggGroup {
   int stage;   // pair form, wpr == 1: the workgroup stages the per-node pre-activations of its scenes in LDS
   int lines;   // fused hyper gather: 1 = accumulated in line layout (agg_x_kernel; needs the launch's `part` LDS),
                // 2 = from the scenes' ori rows staged in that LDS (the workgroup's scenes fit)
+  int spw;     // fused closing stage (a.y != NULL): scenes per workgroup — its edge rows are whole scenes
 };
 
 // eo = H ori of one 32-row block in LINE layout (see scatter_tile_lines in gn_mlp_bf16.hpp for why): lane L = (sub = L / 8,

@@ -1145,6 +1145,7 @@ static int agg_launch(const gn_agg_group_t* groups_in, int n_groups_in, hipStrea
   GroupTable<AggGroup> T{};
   T.n = n_groups;
   int wg = 0;
+  int n_fused = 0;
   for (int g = 0; g < n_groups; ++g) {
     const gn_agg_group_t& G = groups[g];
     if (G.A != nullptr) {
@@ -1165,7 +1166,7 @@ static int agg_launch(const gn_agg_group_t* groups_in, int n_groups_in, hipStrea
     }
     GN_CHECK(need(xm ? (G.A != nullptr ? G.W2x : G.W12x) : (const void*)G.W, true));
     if (G.A == nullptr) GN_CHECK(need(G.b1, true));
-    GN_CHECK(need(G.feat, true));
+    if (G.y == nullptr) GN_CHECK(need(G.feat, true));
     GN_CHECK(need(G.edge_feat, false));
     GN_CHECK(need(G.b2, false));
     if (G.rows <= 0 || G.K < 1 || G.K > GN_MAX_TYPES) return GN_ERR_SHAPE;
@@ -1182,6 +1183,31 @@ static int agg_launch(const gn_agg_group_t* groups_in, int n_groups_in, hipStrea
     if (G.node_form) wpr = 1;
     T.g[g].a = G;
     T.g[g].wpr = wpr;
+    T.g[g].spw = 0;
+    if (G.y != nullptr) {      // fused closing stage
+      ++n_fused;
+      // (the chain is built for two output tiles: 32 < dout <= 64, the image gn_mlp2's kernels take for that width)
+      if (twin || !xm || G.dout <= 32 || G.dout > 64 || G.ldy < G.dout || !(G.divisor != 0.f) || G.N <= 0 || G.N > 16)
+        return GN_ERR_SHAPE;
+      GN_CHECK(need(G.m2x, true));
+      GN_CHECK(need(G.m2bias, true));
+      GN_CHECK(need(G.ori, true));
+      GN_CHECK(need(G.y, false));
+      if (G.A != nullptr) {
+        if (!G.node_form) return GN_ERR_SHAPE;
+      } else {
+        // hyper group: whole scenes per workgroup, at most 64 nodes (two row blocks of the closing chain)
+        if (G.eo != nullptr || G.H == nullptr || G.E > 16 || wpr == 1) return GN_ERR_SHAPE;
+        // (a one-hyperedge module — scale == N — has so few edge rows that 64 nodes per workgroup would multiply its
+        // workgroups sixfold; it takes up to 160 nodes, i.e. five row blocks of the closing chain, per workgroup: the
+        // launch is as long as its waves live, and that depends on how many workgroups share a CU — measured)
+        const int node_cap = G.E == 1 ? 160 : 64;
+        int spw = (128 / wpr) / G.E;
+        if (node_cap / G.N < spw) spw = node_cap / G.N;
+        if (spw < 1) return GN_ERR_SHAPE;
+        T.g[g].spw = spw;
+      }
+    }
     // pair form with one wave per row block: stage the scenes' node rows in LDS when they fit
     const bool no_stage = getenv("GN_AGG_NO_STAGE") != nullptr;
     T.g[g].stage = (!no_stage && G.A != nullptr && wpr == 1 && !G.node_form &&
@@ -1205,9 +1231,11 @@ static int agg_launch(const gn_agg_group_t* groups_in, int n_groups_in, hipStrea
     T.first_wg[g] = wg;
     const gn_agg_group_t& a = T.g[g].a;
     wg += a.node_form ? (a.rows / a.E * a.N + 31) / 32      // one workgroup per 32-NODE row block
-                      : ((a.rows + 31) / 32 * T.g[g].wpr + 3) / 4;
+          : T.g[g].spw > 0 ? (a.rows / a.E + T.g[g].spw - 1) / T.g[g].spw      // fused closing stage: whole scenes
+                           : ((a.rows + 31) / 32 * T.g[g].wpr + 3) / 4;
   }
   T.first_wg[n_groups] = wg;
+  if (n_fused != 0 && n_fused != n_groups) return GN_ERR_SHAPE;      // every group of a launch or none
   // bf16 storage, a large launch: two row blocks per wave (agg_rb2_kernel)
   if (twin) {
     // (pairs of row blocks must still fill the chip: >= 2048 waves in all.  GN_AGG_RB2 = 0 / 1 forces the choice —
@@ -1246,7 +1274,7 @@ static int agg_launch(const gn_agg_group_t* groups_in, int n_groups_in, hipStrea
     const gn_agg_group_t& a = T.g[g].a;
     T.g[g].lines = (xm && !no_lines && a.A == nullptr && a.eo == nullptr && a.H != nullptr && a.N <= 64) ? 1 : 0;
     if (T.g[g].lines && !no_hstage) {
-      const int nodes = pool_stage_nodes(128 / T.g[g].wpr, a.E, a.N);
+      const int nodes = T.g[g].spw > 0 ? T.g[g].spw * a.N : pool_stage_nodes(128 / T.g[g].wpr, a.E, a.N);
       const size_t b = (size_t)nodes * (twin ? PoolStage<__bf16>::kPitch * sizeof(__bf16) : PoolStage<float>::kPitch * sizeof(float));
       if (b <= 44 * 1024) {
         T.g[g].lines = 2;
@@ -1254,6 +1282,8 @@ static int agg_launch(const gn_agg_group_t* groups_in, int n_groups_in, hipStrea
       }
     }
   }
+  for (int g = 0; g < n_groups; ++g)      // the fused closing stage of a hyper group reads its scenes' rows from the stage
+    if (T.g[g].spw > 0 && T.g[g].lines != 2) return GN_ERR_SHAPE;
   bool need_part = false;       // LDS for partial sums (wpr > 1), the staged node rows or the line-layout gather
   for (int g = 0; g < n_groups; ++g) {
     need_part = need_part || T.g[g].wpr > 1 || T.g[g].stage != 0 || T.g[g].lines != 0;
@@ -1264,17 +1294,24 @@ static int agg_launch(const gn_agg_group_t* groups_in, int n_groups_in, hipStrea
     }
   }
   const size_t part_bytes = need_part ? (stage_need > kAggPartBytes ? stage_need : (size_t)kAggPartBytes) : 0;
+  bool any_pair = false;        // a per-pair form of the pairwise graph in this launch: the instantiation that has them
+  for (int g = 0; g < n_groups; ++g) any_pair = any_pair || (groups[g].A != nullptr && !groups[g].node_form);
   if (twin)
-    hipLaunchKernelGGL((agg_x_kernel<1, __bf16>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
+    hipLaunchKernelGGL((agg_x_kernel<1, __bf16, false>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
   else if (xm) {
     const int hm = x_mode(groups, n_groups, [](const gn_agg_group_t& G) {
       return (G.A != nullptr ? G.W2h : G.W12h) != nullptr;
     });
     if (hm < 0) return GN_ERR_SHAPE;
-    if (hm)
-      hipLaunchKernelGGL((agg_x_kernel<2, float>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
+    const dim3 grid(table_xcd_grid(T));
+    if (hm && any_pair)
+      hipLaunchKernelGGL((agg_x_kernel<2, float, true>), grid, dim3(256), part_bytes, stream, T);
+    else if (hm)
+      hipLaunchKernelGGL((agg_x_kernel<2, float, false>), grid, dim3(256), part_bytes, stream, T);
+    else if (any_pair)
+      hipLaunchKernelGGL((agg_x_kernel<3, float, true>), grid, dim3(256), part_bytes, stream, T);
     else
-      hipLaunchKernelGGL((agg_x_kernel<3, float>), dim3(table_xcd_grid(T)), dim3(256), part_bytes, stream, T);
+      hipLaunchKernelGGL((agg_x_kernel<3, float, false>), grid, dim3(256), part_bytes, stream, T);
   } else
     hipLaunchKernelGGL(agg_mlp_kernel, dim3(wg), dim3(256), 0, stream, T);
   return gn_check_launch();

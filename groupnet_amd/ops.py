@@ -898,13 +898,46 @@ def split_bf16(packed: Tensor, out: Optional[Tensor] = None, parts: int = 3) -> 
     return out
 
 
-def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[Tensor]:
+def closing_fusable(items: Sequence[Tuple[object, Tensor, dict, int]], pks2: Sequence[dict]) -> bool:
+    """Can gn_agg_mlp_f32 apply the closing MLPs itself (gn_agg_group_t.y)?  Mirrors the launcher's rules: fp32
+    results on the 16-bit matrix cores, N <= 16, every group the node form of the pairwise graph or a hyper module with
+    the fused gather whose edge rows run more than one wave per row block (< 768 row blocks), a 128 -> 128 -> dout <= 64 MLP."""
+    if not (BF16X6 and closing_fusion_enabled()):
+        return False
+    for (src, ef, pk, K), pk2 in zip(items, pks2):
+        if (pk2["din"], pk2["dh"]) != (2 * FEAT, 128) or not (32 < pk2["dout"] <= 64) or _ximg(pk2, "mlp2", torch.float32) == 0:
+            return False
+        if isinstance(src, PairSpec):
+            if not src.node or src.A.dtype != torch.float32:
+                return False
+        elif isinstance(src, GatherSpec):
+            if src.H is None or src.ori.dtype != torch.float32:
+                return False
+            B, E, N = src.H.shape
+            if N > 16 or E > 16 or (B * E + 31) // 32 >= 768 or (B * E + 31) // 32 < 1:
+                return False
+            if (B * E + 31) // 32 < 128 and K < 4:      # (the launcher would run one wave per row block)
+                return False
+        else:
+            return False
+    return True
+
+
+def closing_fusion_enabled() -> bool:
+    """GN_FUSE_CLOSING=0: the closing MLP as a launch of its own (read per call)."""
+    return os.environ.get("GN_FUSE_CLOSING", "1") != "0"
+
+
+def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]],
+                    closing: Optional[Sequence[Tuple[dict, Optional[Tensor], Tensor]]] = None) -> List[Tensor]:
     """items = [(eo (B,E,64) | GatherSpec | PairSpec, edge_feat (B,E,K) fp32, pk{"W","b1","b2","xi"[,"W2t"]}, K)]
-    -> [feat (B,E,64)] in the storage type of the inputs (bf16 twin: eo / GatherSpec only)."""
+    -> [feat (B,E,64)] in the storage type of the inputs (bf16 twin: eo / GatherSpec only).
+    ``closing`` (see `closing_fusable`): per item (pk of the closing MLP, out or None, ori (B,N,64)) — the launch then also
+    applies y = MLP(cat(H^T feat, ori) / N) and returns [y (B,N,dout)] instead of the features."""
     _groups(len(items))
     arr = (_lib.AggGroup * len(items))()
     outs = []
-    flops = ref_flops = 0
+    flops = ref_flops = flops2 = 0
     dev0 = dt = None
     for g, (eo, edge_feat, pk, K) in enumerate(items):
         wkey = "W"
@@ -941,10 +974,24 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
             raise ValueError("grouped launch: every group must be on the same device and of the same storage type")
         _req(edge_feat, "edge_feat", (B, E, K))
         node = isinstance(eo, (PairSpec, GatherSpec)) and eo.node
-        feat = torch.empty((B, N if node else E, FEAT), dtype=like.dtype, device=like.device)
-        arr[g] = _lib.AggGroup(eo_ptr, edge_feat.data_ptr(), pk[wkey].data_ptr(), pk["b1"].data_ptr(),
-                               pk["b2"].data_ptr(), feat.data_ptr(), B * E, K, *extra)
-        outs.append(feat)
+        if closing is not None:
+            pk2, out2, ori2 = closing[g]
+            _req(ori2, "ori", (B, N, FEAT))
+            y, ldy = _mlp2_out((B, N), pk2["dout"], out2, ori2)
+            if len(extra) == 10:
+                extra = extra + (0,)
+            # (ori: the pairwise group's extra[0] is unused by its node form — the fused stage reads it from there)
+            extra = (ori2.data_ptr(),) + tuple(extra[1:]) + (_ximg(pk2, "mlp2", like.dtype), _himg(pk2, "mlp2", like.dtype),
+                                                             pk2["bias"].data_ptr(), y.data_ptr(), ldy, pk2["dout"], float(N))
+            arr[g] = _lib.AggGroup(eo_ptr, edge_feat.data_ptr(), pk[wkey].data_ptr(), pk["b1"].data_ptr(),
+                                   pk["b2"].data_ptr(), 0, B * E, K, *extra)
+            outs.append(y)
+            flops2 += B * N * 2 * (128 * 128 + 128 * (((pk2["dout"] + 31) // 32) * 32))
+        else:
+            feat = torch.empty((B, N if node else E, FEAT), dtype=like.dtype, device=like.device)
+            arr[g] = _lib.AggGroup(eo_ptr, edge_feat.data_ptr(), pk[wkey].data_ptr(), pk["b1"].data_ptr(),
+                                   pk["b2"].data_ptr(), feat.data_ptr(), B * E, K, *extra)
+            outs.append(feat)
         # executed FLOPs: both layers, or the second layer only in the pair form; node form: layer 2 per node plus the
         # 3 flops (add, max, fma) per pair-member and hidden value that form S
         if node:
@@ -956,7 +1003,7 @@ def agg_mlp_grouped(items: Sequence[Tuple[object, Tensor, dict, int]]) -> List[T
         # the pairwise graph — through both layers of every type
         pairwise = isinstance(eo, PairSpec) or (isinstance(eo, GatherSpec) and eo.H is None)
         ref_flops += B * (N * N if pairwise else E) * K * (2 * 64 * 128 + 2 * 128 * 64 + 2 * 64)
-    flops = (flops, ref_flops)
+    flops = (flops + flops2, ref_flops + flops2)
     # (the scene-form groups of the twins run in their own kernel ahead of the others' launch, on the same stream: forked
     # onto a side stream beside it they were measured at config 4 — single-stream 0.791 -> 0.784 ms, but 4-stream
     # throughput 1.445 -> 1.338 M scenes/s — and the fork was not kept)

@@ -367,6 +367,21 @@ typedef struct {
                            (H^T feat)[n] = sum_k (W2k S[n,k] + b2k c[n,k])
                          i.e. layer 2 once per NODE (B*N rows) instead of once per pair (B*N(N+1)/2 rows), and `feat`
                          receives (H^T feat) (B*N, 64) — what gn_mlp2_f32 takes with E = 0.  rows stays B*E. */
+  /* Fused closing stage (ABI 34; fp32 entry point on the fp16/bf16-core images, N <= 16; for EVERY group of a launch or
+   * for none): with y != NULL the workgroups that finish a scene's aggregate also apply the closing MLP
+   *   y[b*N + n] = W1 relu(W0 cat(H^T feat, ori)[n] / divisor + b0) + b1     (MS_HGNN_batch.py:267, :120 / :355, :220-229)
+   * — what gn_mlp2_f32 would have computed from `feat` in a launch of its own — and `feat` is neither written nor
+   * read (may be NULL).  m2x / m2h / m2bias: gn_mlp2_group_t.Wx / Wh / bias of a 128 -> 128 -> dout MLP, 32 < dout <= 64; y rows
+   * have stride ldy.  Needs ori and, for a hyper group, H / E / N with the fused gather (eo == NULL, E <= 16); a
+   * pairwise group must use node_form.  Groups too large for the per-scene workgroup shapes (more than 767 row blocks
+   * of edge rows) are refused: use the two launches. */
+  const void* m2x;
+  const void* m2h;
+  const float* m2bias;
+  float* y;
+  int ldy;
+  int dout;
+  float divisor;
 } gn_agg_group_t;
 int gn_agg_mlp_f32(const gn_agg_group_t* groups, int n_groups, gn_stream_t stream);
 /* twin: two-layer form only (eo, or the fused gather from ori) — a per-node first layer stored in bf16 would
