@@ -92,7 +92,9 @@ class MultiScaleHGNN(nn.Module):
         # The fused affinity + top-k launch rides as the tail workgroups of the first node-stage launch (one launch and
         # one boundary fewer: -5.5 us of 116 on a dependent chain of forwards at B = 512, N = 11).  A caller that overlaps
         # independent forwards on several streams may prefer it as its own small launch, which fits beside other
-        # streams' kernels (+2.6 % throughput on 4 streams in the same measurement): set False.
+        # streams' kernels (+2.6 % throughput on 4 streams in the same measurement): set False.  The same switch selects
+        # whether the typed-aggregation launch applies the closing MLPs itself (4 launches instead of 5: same latency,
+        # -2 % throughput side by side — `run_message_passing(fuse_closing=)`).
         self.affinity_tail = True
 
     @property
@@ -182,8 +184,10 @@ class MultiScaleHGNN(nn.Module):
         if self.grouped:
             # every stage of the 1+S modules in ONE launch: launches always carry enough workgroups
             # to fill the chip, and nothing depends on how streams map to hardware queues
+            # (latency form — `affinity_tail` — also folds the closing MLPs into the aggregation launch: 4 launches)
             run_message_passing(mods, [f] * (1 + S), [None, *Hs], list(noise_u), cols, join=join,
-                                affinity=tail if (S and ops.fused_affinity_fits(N, D)) else None)
+                                affinity=tail if (S and ops.fused_affinity_fits(N, D)) else None,
+                                fuse_closing=self.affinity_tail)
         else:
             for m, H, u, c in zip(mods, [None, *Hs], noise_u, cols):
                 run_message_passing([m], [f], [H], [u], [c])

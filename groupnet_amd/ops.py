@@ -904,6 +904,8 @@ def closing_fusable(items: Sequence[Tuple[object, Tensor, dict, int]], pks2: Seq
     the fused gather whose edge rows run more than one wave per row block (< 768 row blocks), a 128 -> 128 -> dout <= 64 MLP."""
     if not (BF16X6 and closing_fusion_enabled()):
         return False
+    if os.environ.get("GN_AGG_HSTAGE", "1") == "0" or os.environ.get("GN_AGG_LINES", "1") == "0":
+        return False      # (diagnostic gathers: the fused stage reads its scenes' rows from the LDS stage)
     for (src, ef, pk, K), pk2 in zip(items, pks2):
         if (pk2["din"], pk2["dh"]) != (2 * FEAT, 128) or not (32 < pk2["dout"] <= 64) or _ximg(pk2, "mlp2", torch.float32) == 0:
             return False

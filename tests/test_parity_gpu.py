@@ -1519,11 +1519,12 @@ def test_node_form_switch_changes_the_path_not_the_result(monkeypatch):
     shapes, outs = {}, {}
     real = ops.agg_mlp_grouped
 
-    def spy(items):
-        r = real(items)
+    def spy(items, *a, **k):
+        r = real(items, *a, **k)
         shapes[os.environ.get("GN_NODE_FORM", "1")] = tuple(r[0].shape)
         return r
     monkeypatch.setattr(ops, "agg_mlp_grouped", spy)
+    monkeypatch.setenv("GN_FUSE_CLOSING", "0")      # (the closing stage on its own: the aggregation's output is what is looked at)
     for mode in ("0", "1"):
         monkeypatch.setenv("GN_NODE_FORM", mode)
         G.set_noise_mode("device", seed=11)
@@ -1533,3 +1534,43 @@ def test_node_form_switch_changes_the_path_not_the_result(monkeypatch):
     assert shapes["0"] == (64, 66, 64) and shapes["1"] == (64, 11, 64)
     a, b = outs["0"][0], outs["1"][0]
     assert maxerr(a, b) <= 1e-6 * max(1.0, float(a.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------
+# closing MLP fused into the typed-aggregation launch (gn_agg_group_t.y)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6"])
+@pytest.mark.parametrize("B,N,scales,nmp", [(37, 11, [2, 5, 11], 1), (512, 11, [2, 5, 11], 1), (5, 2, [2], 1), (7, 16, [2, 4], 1),
+                                            (4, 1, [1], 1), (9, 5, [2, 5], 2), (64, 13, [3, 13], 1)])
+def test_closing_stage_fused_into_the_aggregation_launch_is_bit_identical(B, N, scales, nmp, precision, monkeypatch):
+    """gn_agg_group_t.y: the workgroups that finish a scene's aggregate apply the closing MLP themselves (scene-aligned
+    hyper row blocks, LDS scatter in the fused scatter's order, the 4-wave chain of mlp2_xs_body).  The block's latency
+    form (affinity_tail) uses it: no gn_mlp2 launch, rows bit-identical to the two launches; ragged last workgroups,
+    scale == N modules (many scenes per workgroup), one and two node row blocks per workgroup, nmp_layers = 2."""
+    import groupnet_amd as G
+    from groupnet_amd import ops
+    from groupnet_amd.multiscale import MultiScaleHGNN
+    torch.manual_seed(7 * B + N)
+    blk = MultiScaleHGNN(scales, nmp_layers=nmp).to(dev()).eval()
+    f = torch.randn(B, N, 64, device=dev())
+    calls = {"0": 0, "1": 0}
+    real = ops.mlp2_grouped
+
+    def spy(*a, **k):
+        calls[os.environ["GN_FUSE_CLOSING"]] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(ops, "mlp2_grouped", spy)
+    old = ops.precision()
+    ops.set_precision(precision)
+    outs = {}
+    try:
+        for mode in ("0", "1"):
+            monkeypatch.setenv("GN_FUSE_CLOSING", mode)
+            G.set_noise_mode("device", seed=21)
+            with torch.no_grad():
+                outs[mode] = blk(f)[0]
+    finally:
+        ops.set_precision(old)
+        G.set_noise_mode("host")
+    assert calls["0"] >= nmp and calls["1"] == 0
+    assert torch.equal(outs["0"], outs["1"])
