@@ -784,9 +784,9 @@ constexpr int kAggPartBytes = 4 * 32 * (64 + 8) * 4;
 
 // A wave's private walk over L sub-steps whose addresses `at(s)` gives (s a compile-time constant after unrolling):
 // a ring of D sub-steps refilled straight from L2.
-template <int P, int L>
+template <int P, int L, int D_ = (P == 1 ? 8 : 4)>
 struct PStream {
-  static constexpr int D = P == 1 ? 8 : 4;
+  static constexpr int D = D_;
   f32x4 q[D][P];
   template <typename AT>
   __device__ __forceinline__ void begin(AT at) {
@@ -869,18 +869,39 @@ __device__ __forceinline__ int pipe_off_B(int t, int HT, int NA, int NB) {
 // same sums as mlp2_xs_body: bit-identical rows.  (Requesting a wave's 12 sub-steps once per workgroup and keeping them
 // for every row block it closes was measured: 96 / 144 more live registers, 156 bytes of scratch, launch +2 us.)
 constexpr int kXPitch = 128 + 4;
+// a wave's 12 sub-steps of the closing image (hidden tile `wave`: 8 of layer 1, then 4 of layer 2) and the ring that
+// walks them; begin() is called by the workgroup BEFORE it forms the row block's inputs, so that the first sub-steps'
+// L2 round trip runs beside the scatter instead of ahead of the first MFMA
+template <int P>
+struct ClosingStream {
+  const f32x4* segA;
+  const f32x4* segB;
+#ifndef GN_CLOSING_DEPTH
+#define GN_CLOSING_DEPTH 4      // sub-steps in flight.  Four cover ~400 cycles of MFMA work against an L2 round trip of ~1 k
+#endif                          // beside a second workgroup: a row block's chain runs three round trips long (per-wave stamps:
+                                // ~8 k cycles per row block).  Five or more cost the kernel scratch (20 / 80 / 128 bytes per
+                                // lane at 5 / 6 / 8: measured +2 us) — the depth stays at what 254 registers allow.
+  PStream<P, 12, GN_CLOSING_DEPTH> ps;
+  __device__ __forceinline__ void init(const void* image, int wave, int lane, ovf_t& ovf) {
+    if constexpr (P == 2) ovf.wf |= image_flag(image, 48);
+    const f32x4* img = reinterpret_cast<const f32x4*>(image) + lane;
+    segA = img + (size_t)pipe_off_A(wave, 8, 4) * P * 64;
+    segB = img + (size_t)pipe_off_B(wave, 4, 8, 4) * P * 64;
+  }
+  __device__ __forceinline__ const f32x4* at(int s) const { return s < 8 ? segA + s * P * 64 : segB + (s - 8) * P * 64; }
+  __device__ __forceinline__ void begin() {
+    ps.begin([&](int s) { return at(s); });
+  }
+  __device__ __forceinline__ void step(int s, const Parts<P>& x, f32x16& acc) {
+    ps.step(s, [&](int t) { return at(t); }, x, acc);
+  }
+};
 template <int P, typename T>
-__device__ __forceinline__ void closing_chain(const void* image, const float* __restrict__ bias, T* __restrict__ y, int ldy,
+__device__ __forceinline__ void closing_chain(ClosingStream<P>& cs, const float* __restrict__ bias, T* __restrict__ y, int ldy,
                                               int dout, int row0, int nlive, const float* __restrict__ X, f32x4* lds,
                                               int wave, int lane, ovf_t& ovf) {
-  constexpr int IT = 4, HT = 4, OT = 2, NA = 2 * IT, NB = 2 * OT, L = NA + NB;
+  constexpr int IT = 4, HT = 4, OT = 2, NA = 2 * IT, NB = 2 * OT;
   const int h = lane >> 5, r = lane & 31;
-  if constexpr (P == 2) ovf.wf |= image_flag(image, HT * (NA + NB));
-  const f32x4* img = reinterpret_cast<const f32x4*>(image) + lane;
-  const f32x4* segA = img + (size_t)pipe_off_A(wave, NA, NB) * P * 64;
-  const f32x4* segB = img + (size_t)pipe_off_B(wave, HT, NA, NB) * P * 64;
-  auto at = [&](int s) -> const f32x4* { return s < NA ? segA + s * P * 64 : segB + (s - NA) * P * 64; };
-  PStream<P, L> ps;
   {
     f32x16 in;                                       // wave w forms the operand parts of input tile w
     const float* xr = X + r * kXPitch + 32 * wave + 4 * h;
@@ -889,7 +910,6 @@ __device__ __forceinline__ void closing_chain(const void* image, const float* __
       const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 8 * q);
       in[4 * q + 0] = v[0], in[4 * q + 1] = v[1], in[4 * q + 2] = v[2], in[4 * q + 3] = v[3];
     }
-    ps.begin(at);
     put_parts<P>(lds, wave, lane, in, ovf);
   }
   __syncthreads();
@@ -906,7 +926,7 @@ __device__ __forceinline__ void closing_chain(const void* image, const float* __
 #pragma unroll
   for (int u = 0; u < NA; ++u) {
     if (u + 1 < NA) xop(u + 1, xa[(u + 1) & 1]);
-    ps.step(u, at, xa[u & 1], hid);
+    cs.step(u, xa[u & 1], hid);
   }
   f32x16 out[OT], bo[OT];
 #pragma unroll
@@ -922,7 +942,7 @@ __device__ __forceinline__ void closing_chain(const void* image, const float* __
   make_parts<P>(hid, 0, xh[0], ovf);
   make_parts<P>(hid, 1, xh[1], ovf);
 #pragma unroll
-  for (int u = 0; u < NB; ++u) ps.step(NA + u, at, xh[u & 1], out[u >> 1]);
+  for (int u = 0; u < NB; ++u) cs.step(NA + u, xh[u & 1], out[u >> 1]);
   if (wave == 0) {
 #pragma unroll
     for (int o = 0; o < OT; ++o)
@@ -1211,6 +1231,9 @@ __device__ __forceinline__ void agg_node_body(const gn_agg_group_t& G, int wg, i
     // ---- fused closing stage: X = cat(H^T feat, ori) / divisor of the block's 32 nodes in stage buffer 0 (free now),
     // the chain's exchange space in the dynamic part (behind a barrier: the partial outputs are read from there first)
     float* X = stage0;
+    ClosingStream<P> cs;
+    cs.init(pick_image<P>(G.m2x, G.m2h), wave, lane, ovf);
+    cs.begin();
     f32x4 v2[2];
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) {
@@ -1246,8 +1269,8 @@ __device__ __forceinline__ void agg_node_body(const gn_agg_group_t& G, int wg, i
       *reinterpret_cast<f32x4*>(X + row * kXPitch + 96 + 4 * piece) = o1;
     }
     __syncthreads();
-    closing_chain<P, T>(pick_image<P>(G.m2x, G.m2h), G.m2bias, reinterpret_cast<T*>(G.y), G.ldy, G.dout, g0,
-                        rowsN - g0, X, reinterpret_cast<f32x4*>(dyn), wave, lane, ovf);
+    closing_chain<P, T>(cs, G.m2bias, reinterpret_cast<T*>(G.y), G.ldy, G.dout, g0, rowsN - g0, X,
+                        reinterpret_cast<f32x4*>(dyn), wave, lane, ovf);
     GN_STAMP(unit, 3);
     GN_STAMP(unit, 4);
     GN_STAMP(unit, 9);
@@ -1908,7 +1931,10 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
       const int scene0 = wg * spw, B = rows / E;
       const int nodes = min(spw, B - scene0) * N;                  // node rows of this workgroup (>= 1)
       const T* orib = reinterpret_cast<const T*>(G.ori);
+      ClosingStream<P> cs;
+      cs.init(pick_image<P>(G.m2x, G.m2h), wave, lane, ovf);
       for (int nb = 0; nb * 32 < nodes; ++nb) {
+        cs.begin();
         // X[row][0..63] = (sum_e H[b,e,n] feat[b,e]) / divisor in the order of the fused scatter of gn_mlp2 (e ascending,
         // fmaf), X[row][64..127] = ori[b,n] / divisor; thread (row = t / 8, piece = t % 8) forms two 16-byte pieces of each
         const int row = (int)threadIdx.x >> 3, piece = (int)threadIdx.x & 7;
@@ -1916,16 +1942,22 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
         const int sl = m / N, n = m - sl * N;
         const float* hcol = G.H + ((size_t)(scene0 + sl) * E) * N + n;
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        for (int e = 0; e < E; ++e) {
-          const float w = hcol[(size_t)e * N];
-          const float* fr = F + (sl * E + e) * kFPitch + 4 * piece;
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(fr), v1 = *reinterpret_cast<const f32x4*>(fr + 32);
+        // (the node's incidence column first, all of it in flight at once — E <= 16 here: a load per loop iteration cost
+        // one L2 round trip per hyperedge, 8 k cycles per row block in the per-wave stamps)
+        float hw[16];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            a0[c] = fmaf(w, v0[c], a0[c]);
-            a1[c] = fmaf(w, v1[c], a1[c]);
+        for (int e = 0; e < 16; ++e) hw[e] = e < E ? hcol[(size_t)e * N] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (e < E) {
+            const float* fr = F + (sl * E + e) * kFPitch + 4 * piece;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(fr), v1 = *reinterpret_cast<const f32x4*>(fr + 32);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              a0[c] = fmaf(hw[e], v0[c], a0[c]);
+              a1[c] = fmaf(hw[e], v1[c], a1[c]);
+            }
           }
-        }
         const T* orow = orib + ((size_t)scene0 * N + m) * GN_FEAT + 4 * piece;
         f32x4 o0 = ld4(orow), o1 = ld4(orow + 32);
 #pragma unroll
@@ -1941,8 +1973,8 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
         *reinterpret_cast<f32x4*>(xr + 64) = o0;
         *reinterpret_cast<f32x4*>(xr + 96) = o1;
         __syncthreads();
-        closing_chain<P, T>(pick_image<P>(G.m2x, G.m2h), G.m2bias, reinterpret_cast<T*>(G.y), G.ldy, G.dout,
-                            scene0 * N + nb * 32, nodes - nb * 32, X, wring, wave, lane, ovf);
+        closing_chain<P, T>(cs, G.m2bias, reinterpret_cast<T*>(G.y), G.ldy, G.dout, scene0 * N + nb * 32, nodes - nb * 32, X,
+                            wring, wave, lane, ovf);
       }
       GN_STAMP(unit, 4);
       GN_STAMP(unit, 9);

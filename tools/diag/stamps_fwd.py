@@ -68,7 +68,11 @@ def edge_rows(e):
 def edge_units(items, *a, **k):
     return sum(((edge_rows(it[0]) + 127) // 128) * 4 for it in items)
 wrap("edge_mlp_gumbel_grouped", (lambda *a, **k: 8192) if B > 512 else edge_units, (lambda *a, **k: None) if B > 512 else (lambda items, *a, **k: [("pair", slice(0, 1056)), ("hyper", slice(1056, 1056 + 400))]))
-wrap("agg_mlp_grouped", lambda items: 8192 if B > 512 else 4 * 700, (lambda items: None) if B > 512 else (lambda items: [("hyperA", slice(0, 352)), ("hyperB", slice(352, 704)), ("small", slice(704, 768)), ("node", slice(768, 1472))]
+def agg_groups(items, closing=None):
+    if closing is not None:      # fused closing stage: hyper modules 103 workgroups each (5 scenes), scale = N 37 (14 scenes)
+        return [("hyperA", slice(0, 412)), ("hyperB", slice(412, 824)), ("small", slice(824, 972)), ("node", slice(972, 1676))]
+    return None
+wrap("agg_mlp_grouped", lambda items, closing=None: 8192 if B > 512 else 4 * 700, (lambda items, closing=None: None) if B > 512 else (lambda items, closing=None: agg_groups(items, closing) or [("hyperA", slice(0, 352)), ("hyperB", slice(352, 704)), ("small", slice(704, 768)), ("node", slice(768, 1472))]
                                    if any(isinstance(it[0], ops.PairSpec) and it[0].node for it in items) else
                                    [("hyperA", slice(0, 352)), ("hyperB", slice(352, 704)), ("pair", slice(704, 1760)), ("small", slice(1760, 1824))]))
 wrap("mlp2_grouped", lambda items, keep=None: 8192 if B > 512 else (4 * 176 * 4 if os.environ.get("GN_MLP2_XS", "1") != "0" else 4 * 44 * 4), None)
