@@ -779,6 +779,13 @@ __device__ __forceinline__ void add_b2(const float* __restrict__ b2k, float efk,
   out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1, efb, out[1], 0, 0, 0);
 }
 
+// the same with the type's b2 values and ef already in registers (requested one type ahead: loaded where they are used,
+// the ef value and then the two b2 values each cost the wave a full L2 round trip per type — vmcnt counts in order)
+__device__ __forceinline__ void add_b2_regs(float f0, float f1, float efk, int h, f32x16 (&out)[2]) {
+  const float efb = h == 0 ? efk : 0.f;
+  out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? f0 : 0.f, efb, out[0], 0, 0, 0);
+  out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? f1 : 0.f, efb, out[1], 0, 0, 0);
+}
 constexpr int kAggPartBytes = 4 * 32 * (64 + 8) * 4;
 
 
@@ -1092,7 +1099,9 @@ __device__ __forceinline__ void agg_node_body(const gn_agg_group_t& G, int wg, i
   if (K > 1) fetch(1);
   __syncthreads();
   GN_STAMP(unit, 1);
-  __builtin_amdgcn_s_setprio(2);      // (these waves end the launch: their instructions go first where a SIMD is shared)
+  // (these waves end the launch — their instructions go first where a SIMD is shared — unless the closing stage is
+  // fused: then the hyper groups' waves, with two row blocks to close, do)
+  if (G.y == nullptr) __builtin_amdgcn_s_setprio(2);
   f32x16 out[2];
 #pragma unroll
   for (int o = 0; o < 2; ++o)
@@ -1805,10 +1814,14 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
     ws.begin(img, wring, lane, wave, K * 32 / CH);
     f32x16 hid0 = load_bias_tile(b1, h);
     float efk = efrow[0];
+    float bf0 = 0.f, bf1 = 0.f;
+    if constexpr (P != 1) bf0 = b2[lane & 31], bf1 = b2[32 + (lane & 31)];
 #pragma unroll 1
     for (int k = 0; k < K; ++k) {
       const int kc = k + 1 < K ? k + 1 : k;
       const float efk_next = efrow[kc];
+      float bn0 = 0.f, bn1 = 0.f;
+      if constexpr (P != 1) bn0 = b2[kc * 64 + (lane & 31)], bn1 = b2[kc * 64 + 32 + (lane & 31)];
       const f32x16 hid0_next = load_bias_tile(b1 + kc * 128, h);
       if constexpr (P == 1) {
         // VALU-lean form: the type's layer 2 accumulates into a temporary that starts at b2_k, ReLU runs on the
@@ -1823,15 +1836,16 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
 #pragma unroll
           for (int r = 0; r < 16; ++r) out[o][r] = fmaf(efk, tmp[o][r], out[o][r]);
       } else {
-        add_b2(b2 + k * 64, efk, lane, h, out);
+        add_b2_regs(bf0, bf1, efk, h, out);
         layer_pair<P, 2, 2, 4>(ws, k * 32 / CH, 0, xi, hid0, b1 + k * 128, h, out, ovf,
                                [&](int, f32x16& hid) { relu_scale16(hid, efk); });
       }
       hid0 = hid0_next;
-      efk = efk_next;
+      efk = efk_next, bf0 = bn0, bf1 = bn1;
     }
   } else if (any_rows && sub < K) {
     // ---- two-layer form, wpr > 1: types dealt over the waves of a row block, private register rings ------------------
+    if (fused) __builtin_amdgcn_s_setprio(1);
     f32x16 in[2];
     if (G.eo != nullptr) {
       load_rows<2>(reinterpret_cast<const T*>(G.eo), GN_FEAT, rb.row_ld, h, in);
@@ -1852,10 +1866,11 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
     XStream<P> xs;
     xs.begin(Wx + (size_t)sub * 32 * P * 64);
     f32x16 hid0 = load_bias_tile(b1 + sub * 128, h);
+    float efk = efrow[sub], bf0 = b2[sub * 64 + (lane & 31)], bf1 = b2[sub * 64 + 32 + (lane & 31)];
 #pragma unroll 1
     for (int k = sub; k < K; k += wpr) {
       const int kc = k + wpr < K ? k + wpr : k;
-      const float efk = efrow[k];
+      const float efk_next = efrow[kc], bn0 = b2[kc * 64 + (lane & 31)], bn1 = b2[kc * 64 + 32 + (lane & 31)];
       const f32x16 hid0_next = load_bias_tile(b1 + kc * 128, h);
       xs.segment(Wx + (size_t)k * 32 * P * 64, Wx + (size_t)kc * 32 * P * 64, 32);
       if constexpr (P == 1) {
@@ -1868,10 +1883,14 @@ __device__ __forceinline__ void agg_x_body(const GroupTable<AggGroup>& Tb, f32x4
 #pragma unroll
           for (int r = 0; r < 16; ++r) out[o][r] = fmaf(efk, tmp[o][r], out[o][r]);
       } else {
-        add_b2(b2 + k * 64, efk, lane, h, out);
+        if (k == sub + wpr) GN_STAMP(unit, 5);
+        add_b2_regs(bf0, bf1, efk, h, out);
+        if (k == sub + wpr) GN_STAMP(unit, 6);
         layer_pair<P, 2, 2, 4>(xs, 0, 0, xi, hid0, b1 + k * 128, h, out, ovf, [&](int, f32x16& hid) { relu_scale16(hid, efk); });
+        if (k == sub + wpr) GN_STAMP(unit, 7);
       }
       hid0 = hid0_next;
+      efk = efk_next, bf0 = bn0, bf1 = bn1;
     }
   }
   T* feat = reinterpret_cast<T*>(G.feat);

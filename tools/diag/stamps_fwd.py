@@ -42,7 +42,7 @@ def report(tag, n_units, groups=None):
         mid = u[:, 3] - u[:, 2]
         epi = u[:, 4] - u[:, 3]
         if (u[:, 5] > 0).all() and (u[:, 7] > u[:, 5]).all():
-            print(f"  {name:10s} type-1 iteration: top->partners done {np.median(u[:, 6] - u[:, 5]):6.0f}  ->MFMAs issued {np.median(u[:, 7] - u[:, 6]):6.0f} cycles")
+            print(f"  {name:10s} second type: slot 5->6 {np.median(u[:, 6] - u[:, 5]):6.0f}  6->7 {np.median(u[:, 7] - u[:, 6]):6.0f} cycles (min {(u[:, 7] - u[:, 6]).min():6.0f})")
         print(f"  {name:10s} n={len(u):5d} start med/max {np.median(start):5.2f}/{start.max():5.2f}  end med/max {np.median(end):5.2f}/{end.max():5.2f} us |"
               f" cycles: prologue {np.median(pro):6.0f}  body med {np.median(body):6.0f} min {body.min():6.0f} max {body.max():6.0f}  tail {np.median(tail):6.0f} (2->3 {np.median(mid):6.0f}, 3->4 {np.median(epi):6.0f})")
 
