@@ -17,6 +17,7 @@ from __future__ import annotations
 from typing import List, Optional, Sequence, Tuple
 
 import contextlib
+import os
 import torch
 import torch.nn as nn
 
@@ -187,7 +188,7 @@ class MultiScaleHGNN(nn.Module):
             # (latency form — `affinity_tail` — also folds the closing MLPs into the aggregation launch: 4 launches)
             run_message_passing(mods, [f] * (1 + S), [None, *Hs], list(noise_u), cols, join=join,
                                 affinity=tail if (S and ops.fused_affinity_fits(N, D)) else None,
-                                fuse_closing=self.affinity_tail)
+                                fuse_closing=self.affinity_tail or os.environ.get("GN_FUSE_CLOSING") == "2")
         else:
             for m, H, u, c in zip(mods, [None, *Hs], noise_u, cols):
                 run_message_passing([m], [f], [H], [u], [c])

@@ -43,6 +43,12 @@
  *     (NOT hidden-tile-major [A_t B_t]: A_{t+1} is issued between A_t and B_t so that the splitting of hidden tile t
  *     runs in the shadow of the matrix pipe).  Sub-step offset of A_t: t == 0 ? 0 : NA + (t-1)(NA+NB); of B_t:
  *     t < HT-1 ? 2 NA + t (NA+NB) : HT NA + (HT-1) NB, with NA = 2 IT, NB = 2 OT sub-steps (two per 32x32 tile).
+ *   - Node form of the pairwise typed aggregation (gn_agg_group_t.node_form; ABI 33): edge_aggregation.forward reads the
+ *     per-edge feature only as H^T feat (MS_HGNN_batch.py:267) and the type weighting and layer 2 are linear, so the
+ *     launch can evaluate H^T feat directly, layer 2 once per node instead of once per pair — see the field.  gn_mlp2_*
+ *     takes that aggregate with E = 0.
+ *   - Closing stage in the aggregation launch (gn_agg_group_t.y ...; ABI 34): the same launch also applies the closing
+ *     MLP to cat(H^T feat, ori) / divisor — one launch per message-passing stage fewer, rows bit-identical.
  */
 #ifndef GROUPNET_HIP_H
 #define GROUPNET_HIP_H
