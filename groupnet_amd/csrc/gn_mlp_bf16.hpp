@@ -249,8 +249,14 @@ struct XStream {
     const int u = s % D;
     mfma_substep<P>(q[u], x, acc);
     const f32x4* src = s + D < seg ? cur + (size_t)(s + D) * P * 64 : nxt + (size_t)(s + D - seg) * P * 64;
+#ifdef GN_DIAG_HALF_W        // diagnostic builds only (results are wrong): half of the ring's bytes from L2
+    q[u][0] = src[0];
+#pragma unroll
+    for (int p = 1; p < P; ++p) q[u][p] = q[u][0];
+#else
 #pragma unroll
     for (int p = 0; p < P; ++p) q[u][p] = src[p * 64];
+#endif
     // hipcc otherwise sinks the run-ahead loads down to their use and collapses the ring
     if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
   }
